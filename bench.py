@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — def-corr-sample throughput (Mpix·edges/s) of the fused deformable pyramid
+sample on MI355X, with its HBM roofline and the CPU baseline timed beside it.
+
+One STEP = one pass of the hot path (body of CorrBlock.__call__, reference
+droid_slam/modules/corr.py:101-109: 4 pyramid levels x 49 taps per pixel) over one batch
+of synthetic edges: BASELINE config 2 — 48x64 fmap, L=4, r=3, E=20 edges per GPU — ONE
+kernel launch.  With --probe the level-1 uncertainty probe of corr.py:94-99 is timed in
+the step as well.  Inputs are resident in HBM before the timed region.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): factor-graph edges are
+independent, so every rank samples its own E edges (weak scaling, no data-path
+collective); `value` = all ranks' units / max-over-ranks time.  The sharded driver's one
+real exchange — the all-gather of per-edge target/weight before BA
+(factor_graph.py:290-300) — is timed separately and reported under "exchange".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def make_inputs(E, H1, W1, L, radius, seed, device, from_fmaps=True):
+    """SURVEY §8(d) canonical synthetic inputs, generated on `device`."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    rd = 2 * radius + 1
+
+    def randn(*s):
+        return torch.randn(*s, generator=g, device=device, dtype=torch.float32)
+
+    if from_fmaps:  # volume0 = (fmap1/4)^T (fmap2/4), pyramid by avg_pool2d (corr.py:145-152,83-86)
+        f1 = randn(E, 128, H1 * W1) * 0.5 / 4
+        f2 = randn(E, 128, H1 * W1) * 0.5 / 4
+        v = torch.matmul(f1.transpose(1, 2), f2).view(E * H1 * W1, 1, H1, W1)
+        vols = []
+        for l in range(L):
+            vols.append(v.view(E, H1, W1, H1 >> l, W1 >> l).contiguous())
+            v = torch.nn.functional.avg_pool2d(v, 2, stride=2)
+        del f1, f2, v
+    else:
+        vols = [randn(E, H1, W1, H1 >> l, W1 >> l) for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H1, device=device, dtype=torch.float32),
+                            torch.arange(W1, device=device, dtype=torch.float32), indexing="ij")
+    coords = (torch.stack([xs, ys])[None] + 3.0 * randn(E, 2, H1, W1)).contiguous()
+    o0 = 4 * torch.tanh(randn(E, H1, W1, rd, rd, 2))
+    o1 = (4 * torch.tanh(randn(E, H1, W1, rd, rd, 2)) + o0) / 2
+    offs = [o0, o1] + [None] * (L - 2)
+    return vols, coords, offs[:L]
+
+
+def algorithmic_bytes_per_unit(vols, coords, offs, radius, max_edges=4):
+    """A = out bytes + coords + offsets actually read + 4*U, with U = unique in-bounds volume
+    elements one pixel's taps touch, summed over levels and counted exactly from the inputs
+    (SURVEY §8(d)); averaged over the first `max_edges` edges."""
+    E, _, H1, W1 = coords.shape
+    Es = min(E, max_edges)
+    rd = 2 * radius + 1
+    dev = coords.device
+    d = torch.arange(-radius, radius + 1, device=dev)
+    di = d.view(1, 1, 1, rd, 1)
+    dj = d.view(1, 1, 1, 1, rd)
+    U = torch.zeros(Es, H1, W1, device=dev)
+    off_bytes = 0
+    for l, v in enumerate(vols):
+        H2, W2 = v.shape[3], v.shape[4]
+        x0 = (coords[:Es, 0] / 2 ** l).view(Es, H1, W1, 1, 1)
+        y0 = (coords[:Es, 1] / 2 ** l).view(Es, H1, W1, 1, 1)
+        if offs[l] is not None:
+            o = offs[l][:Es].clone()
+            o[:, :, :, radius, radius] = 0
+            ox, oy = o[..., 0] + x0, o[..., 1] + y0
+            off_bytes += rd * rd * 2 * 4
+        else:
+            ox, oy = x0.expand(Es, H1, W1, rd, rd), y0.expand(Es, H1, W1, rd, rd)
+        x1 = torch.floor(ox).long() + di
+        y1 = torch.floor(oy).long() + dj
+        valid = (x1 >= 0) & (x1 < W2) & (y1 >= 0) & (y1 < H2)
+        ids = []
+        for ddy in (0, 1):
+            for ddx in (0, 1):
+                xx, yy = x1 + ddx, y1 + ddy
+                ok = valid & (xx < W2) & (yy < H2)
+                ids.append(torch.where(ok, yy * W2 + xx, torch.full_like(xx, -1)))
+        ids = torch.stack(ids, -1).view(Es, H1, W1, -1)
+        ids, _ = torch.sort(ids, dim=-1)
+        uniq = (ids[..., 1:] != ids[..., :-1]).sum(-1) + 1  # distinct values incl. possibly -1
+        uniq = uniq - (ids[..., 0] < 0).long()
+        U += uniq.float()
+    Umean = float(U.mean())
+    out_bytes = len(vols) * rd * rd * 4
+    return out_bytes + 8 + off_bytes + 4.0 * Umean, Umean
+
+
+def cpu_baseline(E, H1, W1, L, radius, budget_s=12.0):
+    """torch-CPU F.grid_sample formulation (oracle/grid_sample_baseline.py) on all host
+    cores, same input distribution, bounded sample."""
+    from oracle import grid_sample_baseline as G
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Es = min(E, 4)
+    vols, coords, offs = make_inputs(Es, H1, W1, L, radius, 999, torch.device("cpu"), from_fmaps=False)
+    G.defcorr_pyramid(vols, coords, offs, radius)  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        G.defcorr_pyramid(vols, coords, offs, radius)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {
+        "value": Es * H1 * W1 / med / 1e6, "unit": "Mpix·edges/s", "cores": cores, "kind": "port",
+        "sample": "torch-CPU F.grid_sample formulation of the same 4-level pass, E=%d edges of %dx%d, "
+                  "median of %d reps (%.1f s of CPU work)" % (Es, H1, W1, len(times), sum(times)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--edges", type=int, default=20, help="edges per GPU (BASELINE config 2: 20)")
+    ap.add_argument("--probe", action="store_true", help="also time the level-1 uncertainty probe in the step")
+    ap.add_argument("--variant", type=int, default=0, help="LGU_DEFCORR_VARIANT (A/B only)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
+    if args.variant:
+        os.environ["LGU_DEFCORR_VARIANT"] = str(args.variant)
+
+    import lgu_slam_amd
+    lgu_slam_amd._lib.load()
+    ops = lgu_slam_amd.ops
+
+    E, H1, W1, L, R = args.edges, 48, 64, 4, 3
+    vols, coords, offs = make_inputs(E, H1, W1, L, R, 1234 + rank, dev, from_fmaps=not args.randn_volumes)
+    out = torch.empty(E, L * 49, H1, W1, device=dev)
+    coords_half = (coords / 2).contiguous()
+    units = E * H1 * W1
+
+    def step():
+        if args.probe:  # corr.py:94-99 — probe, variance, sigmoid, stateful offset[1] *= mask
+            probe, = ops.corr_index_forward(vols[1], coords_half, 1)
+            mask = torch.sigmoid(torch.var(probe.permute(0, 3, 4, 1, 2), dim=[3, 4])).view(E, H1, W1, 1, 1, 1)
+            offs[1].mul_(mask)
+        ops.defcorr_pyramid_forward(vols, coords, offs, R, out=out)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # kernels are enqueued on torch's current stream, which these events time
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * units / (wall / args.steps) / 1e6
+
+    exchange = None
+    if world > 1:  # the sharded driver's per-BA-step all-gather of target+weight (E,ht,wd,2)x2
+        import torch.distributed as dist
+        mine = torch.randn(E, H1, W1, 4, device=dev)
+        allv = torch.empty(world * E, H1, W1, 4, device=dev)
+        for _ in range(5):
+            dist.all_gather_into_tensor(allv, mine)
+        barrier()
+        t1 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            dist.all_gather_into_tensor(allv, mine)
+        barrier()
+        ag = (time.perf_counter() - t1) / reps
+        t = torch.tensor([ag], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange = {"op": "all_gather(target,weight) over RCCL", "bytes_per_rank": mine.numel() * 4,
+                    "ms": float(t.item()) * 1e3}
+
+    if rank == 0:
+        A, U = algorithmic_bytes_per_unit(vols, coords, offs, R)
+        kern_s = dev_ms * 1e-3 / args.steps  # average launch-to-launch device time of the step
+        achieved = A * units / kern_s / 1e9
+        res = {
+            "metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)",
+            "value": value, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: TartanAir-mono shape, 48x64 fmap, L=4, r=3, "
+                                   "%d edges per GPU, fused 4-level deformable sample%s" % (E, " + level-1 probe" if args.probe else ""),
+                       "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
+                       "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_unit": A, "unique_volume_elements_per_unit": U,
+                         "kernel": "defcorr_pyr_kernel<3,1,1>", "device_ms_per_step": dev_ms / args.steps},
+            "cpu_baseline": None if args.no_cpu else cpu_baseline(E, H1, W1, L, R),
+        }
+        if exchange:
+            res["exchange"] = exchange
+        print(json.dumps(res, ensure_ascii=False))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/*
+ * lgu_corr.h — C ABI of the MI355X (gfx950) deformable correlation-sampling library.
+ *
+ * This is the drop-in boundary for LGU-SLAM's hot path: every entry point below
+ * replaces one Python-visible operator of the reference's two CUDA extensions
+ * (`defCorrSample`, reference offersample_LGS/droid.cpp:138-147, and the two
+ * `altcorr_*` operators of `droid_backends`, reference src/droid.cpp:246-247).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into a dense, contiguous fp32 buffer owned by
+ *     the caller (PyTorch's allocator in practice); the library never allocates,
+ *     frees or retains memory;
+ *   - the work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream, which is what the reference launches on);
+ *   - the return value is 0 on success, a hipError_t value if the launch failed, or
+ *     one of the LGU_E_* codes below for arguments the kernels cannot serve;
+ *     nothing throws; lgu_error_string() names any code;
+ *   - re-entrant, no mutable global state;
+ *   - "fully written" outputs need no initialisation by the caller; "accumulated"
+ *     outputs must be zero-filled by the caller before the call (the reference
+ *     allocates them with torch::zeros / zeros_like).
+ *
+ * Index conventions follow the reference: tap index i moves in x (width), j in y
+ * (height); rd = 2*radius+1.
+ */
+#ifndef LGU_CORR_H
+#define LGU_CORR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGU_OK 0
+#define LGU_E_BADARG 100001     /* null pointer / non-positive size / radius out of range */
+#define LGU_E_UNSUPPORTED 100002 /* shape the kernels do not serve (e.g. C % 32 != 0) */
+
+#define LGU_MAX_LEVELS 8
+#define LGU_MAX_RADIUS 7
+
+/* Library identification: "lgu_corr <semver> gfx950". */
+const char* lgu_version(void);
+/* Static string for a code returned by any entry point (LGU_E_* or hipError_t). */
+const char* lgu_error_string(int code);
+
+/* ---- volume path -------------------------------------------------------------- */
+
+/* defCorrSample.defCorr_index_forward   (reference offersample_LGS/droid.cpp:53-63,
+ * defCorrSample_kernel.cu:25-91,165-196).
+ *   volume (E,H1,W1,H2,W2)  coords (E,2,H1,W1)  offset (E,H1,W1,rd,rd,2) IN/OUT
+ *   corr   (E,rd,rd,H1,W1)  fully written (masked taps are written as 0).
+ * Side effect kept from the reference: offset[e][y][x][r][r][0:2] = 0. */
+int lgu_defcorr_fwd_f32(const float* volume, const float* coords, float* offset, float* corr,
+                        int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* defCorrSample.defCorr_index_backward  (droid.cpp:65-77, defCorrSample_kernel.cu:93-162,198-231).
+ *   corr_grad (E,rd,rd,H1,W1); volume_grad like volume — ACCUMULATED (caller zero-fills);
+ *   offset_grad like offset — fully written (0 for masked taps). offset centre re-zeroed. */
+int lgu_defcorr_bwd_f32(const float* volume, const float* coords, float* offset,
+                        const float* corr_grad, float* volume_grad, float* offset_grad,
+                        int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* defCorrSample.corr_index_forward      (droid.cpp:79-87, corrSample_kernel.cu:24-82,139-168). */
+int lgu_corridx_fwd_f32(const float* volume, const float* coords, float* corr,
+                        int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* defCorrSample.corr_index_backward     (droid.cpp:89-99, corrSample_kernel.cu:84-136,170-199).
+ *   volume_grad ACCUMULATED (caller zero-fills). `volume` is accepted for signature
+ *   fidelity and never read (the reference kernel does not read it either). */
+int lgu_corridx_bwd_f32(const float* volume, const float* coords, const float* corr_grad,
+                        float* volume_grad,
+                        int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* defCorrSample.gaussianMask            (droid.cpp:100-110, gaussianAttn.cu:19-68,134-163).
+ *   means, covs (E,H1,W1,2); volume, volume1 (E,H1,W1,H2,W2); volume1 fully written
+ *   (zero outside the (2*radius+1)^2 window around floor(mean)). */
+int lgu_gaussmask_fwd_f32(const float* means, const float* covs, const float* volume,
+                          float* volume1,
+                          int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* defCorrSample.gaussianMask_backward   (droid.cpp:112-123, gaussianAttn.cu:72-131,165-200).
+ *   means_grad, covs_grad (E,H1,W1,2) fully written. */
+int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* volume,
+                          const float* volume1_grad, float* means_grad, float* covs_grad,
+                          int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* Fused multi-level deformable sample = the body of CorrBlock.__call__
+ * (reference droid_slam/modules/corr.py:88-109): L calls of defCorr_index_forward on the
+ * L pyramid levels with coords / 2^l, written straight into the concatenated tensor
+ *   out (E, L*rd*rd, H1, W1)   channel = l*rd*rd + i*rd + j     (corr.py:103,109).
+ * volumes[l] (E,H1,W1,H2[l],W2[l]); offsets[l] (E,H1,W1,rd,rd,2) IN/OUT (centre zeroed) or
+ * NULL = structurally zero offsets for that level (corr.py:132-135), nothing is read.
+ * The pointer/size tables are HOST arrays of length L (copied at launch).
+ * flags: LGU_PYR_PROBE fuses the uncertainty probe of corr.py:94-99 as well: the 3x3
+ *   plain sample of level 1 at coords/2, its unbiased variance over the 9 taps,
+ *   mask = sigmoid(var), offsets[1] *= mask written back (the reference's stateful
+ *   update) before level 1 is sampled. Requires L >= 2 and offsets[1] != NULL. */
+#define LGU_PYR_PROBE 1
+int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords,
+                                float* const* offsets, float* out,
+                                int L, int E, int H1, int W1, const int* H2, const int* W2,
+                                int radius, int flags, void* stream);
+
+/* ---- low-memory (on-the-fly correlation) path ---------------------------------- */
+
+/* defCorrSample.lowMem_defSample        (droid.cpp:124-136, lowMem_defSample.cu:27-134,137-168).
+ *   fmap1 (B,H1,W1,C)  fmap2 (B,H2,W2,C)  coords (B,S,H1,W1,2) [x,y interleaved]
+ *   offset (NO,H1,W1,rd,rd,2) IN/OUT — indexed with b*s exactly as the reference does
+ *   (lowMem_defSample.cu:80-83), i.e. offset[0] for every b when S == 1;
+ *   corr (B,S,rd,rd,H1,W1) fully written. Requires C % 32 == 0 and (B-1)*(S-1) < NO. */
+int lgu_lowmem_defsample_fwd_f32(const float* fmap1, const float* fmap2, const float* coords,
+                                 float* offset, float* corr,
+                                 int B, int S, int H1, int W1, int H2, int W2, int C, int NO,
+                                 int radius, void* stream);
+
+/* droid_backends.altcorr_forward        (src/droid.cpp:193-203, src/altcorr_kernel.cu:27-149,290-319).
+ *   corr (B,S,rd*rd,H1,W1), channel = ix*rd + iy, fully written. Requires C % 32 == 0. */
+int lgu_altcorr_fwd_f32(const float* fmap1, const float* fmap2, const float* coords, float* corr,
+                        int B, int S, int H1, int W1, int H2, int W2, int C,
+                        int radius, void* stream);
+
+/* droid_backends.altcorr_backward       (src/droid.cpp:205-217, src/altcorr_kernel.cu:152-286,321-356).
+ *   fmap1_grad (B,H1,W1,C) fully written; fmap2_grad (B,H2,W2,C) ACCUMULATED with float
+ *   atomics (caller zero-fills); coords_grad is never written by the reference and is
+ *   not part of this ABI (the host shim returns zeros). */
+int lgu_altcorr_bwd_f32(const float* fmap1, const float* fmap2, const float* coords,
+                        const float* corr_grad, float* fmap1_grad, float* fmap2_grad,
+                        int B, int S, int H1, int W1, int H2, int W2, int C,
+                        int radius, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGU_CORR_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of liblgu_corr.so (C ABI declared in include/lgu_corr.h).
+
+There is NO fallback: if the shared library is missing or fails to load, every
+operator raises.  Build it with `python __graft_entry__.py build` (or
+`lgu_slam_amd._build.build()`), which needs only hipcc.
+"""
+import ctypes
+import os
+
+from . import _build
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+# name -> argument types (return type is always int)
+SIGNATURES = {
+    "lgu_defcorr_fwd_f32": [_vp, _vp, _vp, _vp] + [_int] * 6 + [_vp],
+    "lgu_defcorr_bwd_f32": [_vp] * 6 + [_int] * 6 + [_vp],
+    "lgu_corridx_fwd_f32": [_vp, _vp, _vp] + [_int] * 6 + [_vp],
+    "lgu_corridx_bwd_f32": [_vp] * 4 + [_int] * 6 + [_vp],
+    "lgu_gaussmask_fwd_f32": [_vp] * 4 + [_int] * 6 + [_vp],
+    "lgu_gaussmask_bwd_f32": [_vp] * 6 + [_int] * 6 + [_vp],
+    "lgu_defcorr_pyramid_fwd_f32": [ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int,
+                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _vp],
+    "lgu_lowmem_defsample_fwd_f32": [_vp] * 5 + [_int] * 9 + [_vp],
+    "lgu_altcorr_fwd_f32": [_vp] * 4 + [_int] * 8 + [_vp],
+    "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],
+}
+
+_lib = None
+
+
+class LguLibraryError(RuntimeError):
+    pass
+
+
+def so_path():
+    return _build.SO_PATH
+
+
+def load():
+    """Load the HIP library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = so_path()
+    if not os.path.exists(path):
+        raise LguLibraryError(
+            "lgu_slam_amd: %s is missing — the gfx950 HIP kernels are not built and there is no CPU "
+            "fallback. Run `python __graft_entry__.py build`." % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:  # pragma: no cover - depends on the ROCm install
+        raise LguLibraryError("lgu_slam_amd: cannot load %s: %s" % (path, exc)) from exc
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, let it surface
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.lgu_version.restype = ctypes.c_char_p
+    lib.lgu_error_string.restype = ctypes.c_char_p
+    lib.lgu_error_string.argtypes = [_int]
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().lgu_error_string(code).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+def version():
+    return load().lgu_version().decode()

@@ -1,0 +1,230 @@
+"""Host-side correlation blocks: this build's counterpart of the reference glue
+(droid_slam/modules/corr.py) over the gfx950 operators in `ops`.
+
+Same public surface as the reference — `CorrSampler`, `DefCorrSampler`,
+`per_Corr_Normalization`, `CorrBlock(ofsMap, ofs_residual, GA, fmap1, fmap2, num_levels,
+radius)`, `AltCorrBlock(ofsMap, ofs_residual, GA, fmaps, num_levels, radius)` with
+`__call__`, `cat`, `__getitem__` — so droid_slam/factor_graph.py:121-123,215,262-279 can
+use it unchanged.  What differs is underneath: in inference `CorrBlock.__call__` issues ONE
+fused launch for the whole pyramid (ops.defcorr_pyramid_forward) instead of four sampler
+launches and a torch.cat, and never reads the offset tensors of levels that are zero by
+construction.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+class CorrSampler(torch.autograd.Function):
+    """Plain bilinear window sampler (reference corr.py:10-24)."""
+
+    @staticmethod
+    def forward(ctx, volume, coords, radius):
+        ctx.save_for_backward(volume, coords)
+        ctx.radius = radius
+        corr, = ops.corr_index_forward(volume, coords, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        volume, coords = ctx.saved_tensors
+        grad_volume, = ops.corr_index_backward(volume, coords, grad_output.contiguous(), ctx.radius)
+        return grad_volume, None, None
+
+
+class DefCorrSampler(torch.autograd.Function):
+    """Deformable sampler (reference corr.py:26-42): grads for volume and offset only."""
+
+    @staticmethod
+    def forward(ctx, volume, coords, offset, radius):
+        offset = offset.float()
+        volume = volume.float()
+        ctx.save_for_backward(volume, coords, offset)
+        ctx.radius = radius
+        corr, = ops.defCorr_index_forward(volume, coords, offset, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        volume, coords, offset = ctx.saved_tensors
+        grad_volume, grad_offset = ops.defCorr_index_backward(volume, coords, offset, grad_output.contiguous(),
+                                                              ctx.radius)
+        return grad_volume, None, grad_offset, None
+
+
+def per_Corr_Normalization(x, normalIndex, eps=1e-5):
+    """Per-sample standardisation over `normalIndex` with biased variance (reference corr.py:44-51)."""
+    mean = x.mean(dim=normalIndex, keepdim=True)
+    std = torch.sqrt(x.var(dim=normalIndex, unbiased=False, keepdim=True) + eps)
+    return (x - mean) / std
+
+
+def generate_offsets(ofsMap, ofs_residual, feats, num_levels):
+    """Learned sampling offsets (reference corr.py:117-135 / :217-235).
+
+    feats (E,256,h,w).  Level 0: 4*tanh(PCN(ofsMap(feats))).  Level 1: the residual head on
+    the 2x-pooled features, nearest-upsampled, (4*tanh(PCN(.)) + level0) / 2.  Levels >= 2
+    are zero by construction.  Returned channel-last: list of (E,h,w,2*rd*rd) tensors, and
+    a list of flags marking the structurally-zero levels.
+    """
+    _, _, h, w = feats.shape
+    o0 = ofsMap(feats)
+    o1 = F.interpolate(ofs_residual(F.avg_pool2d(feats, kernel_size=2, stride=2)), (h, w))
+    o0 = torch.tanh(per_Corr_Normalization(o0, [1, 2, 3])) * 4
+    o1 = (torch.tanh(per_Corr_Normalization(o1, [1, 2, 3])) * 4 + o0) / 2
+    offsets = [o0.permute(0, 2, 3, 1), o1.permute(0, 2, 3, 1)]
+    zero = [False, False]
+    for _ in range(2, num_levels):
+        offsets.append(torch.zeros_like(offsets[0]).detach())
+        zero.append(True)
+    return offsets[:num_levels], zero[:num_levels]
+
+
+def _uncertainty_mask(probe):
+    """sigmoid of the unbiased variance over the 3x3 probe taps (reference corr.py:95-97).
+    probe (E,3,3,h,w) -> (E,h,w,1)."""
+    E, _, _, h, w = probe.shape
+    var = torch.var(probe.permute(0, 3, 4, 1, 2), dim=[3, 4])
+    return torch.sigmoid(var).view(E, h, w, 1)
+
+
+class CorrBlock:
+    """All-pairs correlation volume pyramid + deformable lookup (reference corr.py:52-152)."""
+
+    def __init__(self, ofsMap, ofs_residual, GA, fmap1, fmap2, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.GA = GA
+        self.ofsMap = ofsMap
+        self.ofs_residual = ofs_residual
+
+        b, n, ch, h, w = fmap1.shape
+        volume = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w).float()
+        feats = torch.cat((fmap1.reshape(b * n, ch, h, w), fmap2.reshape(b * n, ch, h, w)), dim=1)
+        self.t = feats
+        self.offset, self._zero_level = generate_offsets(ofsMap, ofs_residual, feats, num_levels)
+
+        self.t = feats.permute(0, 2, 3, 1).contiguous()
+        volume, mean_n, det = GA(self.t, volume)
+        self.mean_n = mean_n.view(b, n, h, w, 2)
+        self.theta = 2 * det.view(b, n, h, w)
+
+        # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
+        self.corr_pyramid = []
+        lvl = volume.reshape(b * n * h * w, 1, h, w)
+        for i in range(num_levels):
+            self.corr_pyramid.append(lvl.view(b * n, h, w, h // 2 ** i, w // 2 ** i))
+            lvl = F.avg_pool2d(lvl, 2, stride=2)
+
+    # ---- lookup ----
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        E = batch * num
+        rd = 2 * self.radius + 1
+        coords = coords.permute(0, 1, 4, 2, 3).contiguous().view(E, 2, ht, wd)
+
+        # uncertainty probe on level 1; the mask is folded into offset[1] and PERSISTS across
+        # calls, exactly like the reference (corr.py:94-99)
+        probe = CorrSampler.apply(self.corr_pyramid[1], coords / 2, 1)
+        self.offset[1] = self.offset[1] * _uncertainty_mask(probe)
+
+        needs_grad = torch.is_grad_enabled() and (
+            any(v.requires_grad for v in self.corr_pyramid) or any(o.requires_grad for o in self.offset))
+        if needs_grad:
+            out = [DefCorrSampler.apply(self.corr_pyramid[i], coords / 2 ** i,
+                                        self.offset[i].contiguous().view(E, ht, wd, rd, rd, 2), self.radius)
+                   .view(batch, num, -1, ht, wd) for i in range(self.num_levels)]
+            return torch.cat(out, dim=2), self.mean_n, self.theta
+
+        offs = []
+        for i in range(self.num_levels):
+            if self._zero_level[i]:
+                offs.append(None)
+                continue
+            o = self.offset[i]
+            if o.dtype != torch.float32 or not o.is_contiguous():
+                o = o.float().contiguous()
+                self.offset[i] = o  # keep the buffer the kernel zeroes the centre of
+            offs.append(o.view(E, ht, wd, rd, rd, 2))
+        pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
+        out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius)
+        return out.view(batch, num, -1, ht, wd), self.mean_n, self.theta
+
+    def cat(self, other):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
+            self.offset[i] = torch.cat([self.offset[i], other.offset[i]], 0)
+            self._zero_level[i] = self._zero_level[i] and other._zero_level[i]
+        return self
+
+    def __getitem__(self, index):
+        for i in range(self.num_levels):
+            self.corr_pyramid[i] = self.corr_pyramid[i][index]
+            self.offset[i] = self.offset[i][index]
+        return self
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """All-pairs correlation (reference corr.py:144-152): (b,n,1,h*w,h,w), both maps / 4."""
+        batch, num, dim, ht, wd = fmap1.shape
+        f1 = fmap1.reshape(batch * num, dim, ht * wd) / 4.0
+        f2 = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
+        return torch.matmul(f1.transpose(1, 2), f2).view(batch, num, 1, ht * wd, ht, wd)
+
+
+class AltCorrBlock:
+    """Low-memory lookup: correlations recomputed from feature maps (reference corr.py:155-249)."""
+
+    def __init__(self, ofsMap, ofs_residual, GA, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.GA = GA  # stored, never applied on this path (reference corr.py:156-158,174-215)
+        self.ofsMap = ofsMap
+        self.ofs_residual = ofs_residual
+        self.offset = []
+
+        B, N, C, H, W = fmaps.shape
+        lvl = fmaps.view(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(num_levels):
+            self.pyramid.append(lvl.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
+            lvl = F.avg_pool2d(lvl, 2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        rd = 2 * self.radius + 1
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+
+        f1 = self.pyramid[0][:, ii]
+        f1 = f1.reshape((B * N,) + f1.shape[2:])
+        f2_0 = self.pyramid[0][:, jj]
+        f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
+        # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
+        feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float()
+        self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+
+        f1 = f1.float().contiguous()
+        out = []
+        for i in range(self.num_levels):
+            f2 = self.pyramid[i][:, jj]
+            f2 = f2.reshape((B * N,) + f2.shape[2:]).float().contiguous()
+            coords_i = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
+            if i == 1:
+                probe, = ops.altcorr_forward(f1, f2, coords_i, 1)
+                probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)  # needs B = S = 1, as in the reference
+                mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
+                self.offset[1] = self.offset[1] * mask
+            off = self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
+            corr, = ops.lowMem_defSample(f1, f2, coords_i, off, self.radius)
+            out.append(corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
+        return torch.cat(out, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze = coords.dim() == 5
+        if squeeze:
+            coords = coords.unsqueeze(dim=-2)
+        corr = self.corr_fn(coords, ii, jj)
+        if squeeze:
+            corr = corr.squeeze(dim=-1)
+        return corr.contiguous()

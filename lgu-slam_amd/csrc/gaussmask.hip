@@ -1,0 +1,180 @@
+// gaussmask.hip — learnable per-pixel 2-D Gaussian window on the level-0 correlation volume.
+//
+// Replaces (reference, relative to /root/reference):
+//   offersample_LGS/gaussianAttn.cu:19-68    gaussianMask_kernel           (host :134-163)
+//   offersample_LGS/gaussianAttn.cu:72-131   gaussianMask_kernel_backward  (host :165-200)
+//
+// Forward is write-bound: the op's contract is a full zero-filled copy-shaped output with
+// a (2R+1)^2 window of re-weighted values per pixel slice.  The reference memsets the
+// output (torch::zeros_like) and then scatters 81 4-byte stores per thread with a 12 KiB
+// lane stride.  Here ONE pass writes every slice exactly once with 16-byte coalesced
+// stores: a workgroup owns SLICES consecutive slices, each thread produces whole float4
+// granules and only the granules that intersect the window read the input volume.
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+// exp(f1) of gaussianAttn.cu:59-62 in the reference's evaluation order.  The reference's
+// `-0.5*(...)` promotes the float sum to double, scales by 0.5 (exact) and narrows back:
+// identical to a float multiply, so no fp64 is needed here.
+__device__ __forceinline__ float gauss_e(int x1, int y1, float mx, float my, float c1, float c2) {
+  const float ddx = (float)x1 - mx, ddy = (float)y1 - my;
+  const float temp1 = ddx / c1, temp2 = ddy / c2;
+  const float f1 = -0.5f * (temp1 * ddx + temp2 * ddy);
+  return expf(f1);
+}
+
+constexpr int GM_THREADS = 256;
+
+__global__ __launch_bounds__(GM_THREADS) void gaussmask_fwd_kernel(const float* __restrict__ means,
+                                                                   const float* __restrict__ covs,
+                                                                   const float* __restrict__ volume,
+                                                                   float* __restrict__ volume1, size_t npix, int H2,
+                                                                   int W2, int r, int slices_per_block) {
+  const int HW2 = H2 * W2;
+  const int g_per_slice = HW2 >> 2;  // W2 % 4 == 0 on this path
+  const int g_per_row = W2 >> 2;
+  const size_t pix0 = (size_t)blockIdx.x * slices_per_block;
+  for (int s = 0; s < slices_per_block; s++) {
+    const size_t pix = pix0 + s;
+    if (pix >= npix) return;
+    const float mx = means[pix * 2 + 0], my = means[pix * 2 + 1];  // wave-uniform
+    const float c1 = covs[pix * 2 + 0], c2 = covs[pix * 2 + 1];
+    const int cx = (int)floorf(mx), cy = (int)floorf(my);
+    const int xa = cx - r, xb = cx + r, ya = cy - r, yb = cy + r;  // window, inclusive
+    const float4* vin = reinterpret_cast<const float4*>(volume + pix * (size_t)HW2);
+    float4* vout = reinterpret_cast<float4*>(volume1 + pix * (size_t)HW2);
+    for (int gi = threadIdx.x; gi < g_per_slice; gi += GM_THREADS) {
+      const int row = gi / g_per_row;
+      const int x4 = (gi - row * g_per_row) << 2;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row >= ya && row <= yb && x4 + 3 >= xa && x4 <= xb) {
+        const float4 v = vin[gi];
+        // :65  volume * 3 * exp_comp, left to right
+        if (x4 + 0 >= xa && x4 + 0 <= xb) o.x = v.x * 3.0f * gauss_e(x4 + 0, row, mx, my, c1, c2);
+        if (x4 + 1 >= xa && x4 + 1 <= xb) o.y = v.y * 3.0f * gauss_e(x4 + 1, row, mx, my, c1, c2);
+        if (x4 + 2 >= xa && x4 + 2 <= xb) o.z = v.z * 3.0f * gauss_e(x4 + 2, row, mx, my, c1, c2);
+        if (x4 + 3 >= xa && x4 + 3 <= xb) o.w = v.w * 3.0f * gauss_e(x4 + 3, row, mx, my, c1, c2);
+      }
+      vout[gi] = o;
+    }
+  }
+}
+
+// Any W2 / unaligned buffers: one thread per output element.
+__global__ __launch_bounds__(256) void gaussmask_fwd_generic_kernel(const float* __restrict__ means,
+                                                                    const float* __restrict__ covs,
+                                                                    const float* __restrict__ volume,
+                                                                    float* __restrict__ volume1, size_t npix, int H2,
+                                                                    int W2, int r) {
+  const size_t HW2 = (size_t)H2 * W2;
+  const size_t total = npix * HW2;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = idx / HW2;
+    const int rem = (int)(idx - pix * HW2);
+    const int y1 = rem / W2, x1 = rem - y1 * W2;
+    const float mx = means[pix * 2 + 0], my = means[pix * 2 + 1];
+    const int cx = (int)floorf(mx), cy = (int)floorf(my);
+    float o = 0.0f;
+    if (x1 >= cx - r && x1 <= cx + r && y1 >= cy - r && y1 <= cy + r)
+      o = volume[idx] * 3.0f * gauss_e(x1, y1, mx, my, covs[pix * 2 + 0], covs[pix * 2 + 1]);
+    volume1[idx] = o;
+  }
+}
+
+// Backward: one wave per pixel, lanes over the window taps, sums reduced across the wave.
+// The reference accumulates the (2R+1)^2 terms sequentially per thread; a tree sum differs
+// from that only by fp32 rounding (tests: 1e-5 relative to the gradient scale).
+// The two `0.5` literals of gaussianAttn.cu:119,121 make those products double
+// expressions in the reference; they are evaluated in double here as well.
+__global__ __launch_bounds__(256) void gaussmask_bwd_kernel(const float* __restrict__ means,
+                                                            const float* __restrict__ covs,
+                                                            const float* __restrict__ volume,
+                                                            const float* __restrict__ volume1_grad,
+                                                            float* __restrict__ means_grad,
+                                                            float* __restrict__ covs_grad, size_t npix, int H2, int W2,
+                                                            int r) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const size_t pix = (size_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int rd = 2 * r + 1, nt = rd * rd;
+  const float mx = means[pix * 2 + 0], my = means[pix * 2 + 1];
+  const float c1 = covs[pix * 2 + 0], c2 = covs[pix * 2 + 1];
+  const int cx = (int)floorf(mx), cy = (int)floorf(my);
+  const float* V = volume + pix * (size_t)H2 * W2;
+  const float* G = volume1_grad + pix * (size_t)H2 * W2;
+  float mg0 = 0.f, mg1 = 0.f, cg0 = 0.f, cg1 = 0.f;
+  for (int t = lane; t < nt; t += kWave) {
+    const int i = t / rd, j = t - i * rd;
+    const int x1 = cx - r + i, y1 = cy - r + j;
+    if (in_bounds(y1, x1, H2, W2)) {
+      const float ddx = (float)x1 - mx, ddy = (float)y1 - my;
+      const float e = gauss_e(x1, y1, mx, my, c1, c2);
+      const float v = V[(size_t)y1 * W2 + x1], g = G[(size_t)y1 * W2 + x1];
+      mg0 += 3.0f * v * (e * ddx / c1) * g;  // :116
+      mg1 += 3.0f * v * (e * ddy / c2) * g;  // :117
+      const float dE1 = (float)((double)e * 0.5 * (double)ddx * (double)ddx / (double)(c1 * c1));  // :119
+      const float dE2 = (float)((double)e * 0.5 * (double)ddy * (double)ddy / (double)(c2 * c2));  // :121
+      cg0 += (3.0f * v * dE1) * g;  // :124
+      cg1 += (3.0f * v * dE2) * g;  // :125
+    }
+  }
+  mg0 = wave_sum_f32(mg0);
+  mg1 = wave_sum_f32(mg1);
+  cg0 = wave_sum_f32(cg0);
+  cg1 = wave_sum_f32(cg1);
+  if (lane == 0) {
+    means_grad[pix * 2 + 0] = mg0;
+    means_grad[pix * 2 + 1] = mg1;
+    covs_grad[pix * 2 + 0] = cg0;
+    covs_grad[pix * 2 + 1] = cg1;
+  }
+}
+
+}  // namespace lgu
+
+extern "C" {
+
+int lgu_gaussmask_fwd_f32(const float* means, const float* covs, const float* volume, float* volume1, int E, int H1,
+                          int W1, int H2, int W2, int radius, void* stream) {
+  using namespace lgu;
+  if (!means || !covs || !volume || !volume1) return LGU_E_BADARG;
+  if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t npix = (size_t)E * H1 * W1;
+  const bool fast = (W2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(volume1)) & 15) == 0;
+  if (fast) {
+    // a 256-thread block writes >= 16 KiB: enough stores in flight per block, few blocks idle
+    const int g_per_slice = (H2 * W2) >> 2;
+    int spb = (4 * GM_THREADS + g_per_slice - 1) / g_per_slice;
+    if (spb < 1) spb = 1;
+    const size_t grid = (npix + spb - 1) / spb;
+    hipLaunchKernelGGL(gaussmask_fwd_kernel, dim3((unsigned)grid), dim3(GM_THREADS), 0, st, means, covs, volume,
+                       volume1, npix, H2, W2, radius, spb);
+  } else {
+    const size_t total = npix * H2 * W2;
+    const size_t want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 65536u * 8 ? want : 65536u * 8);
+    hipLaunchKernelGGL(gaussmask_fwd_generic_kernel, dim3(grid), dim3(256), 0, st, means, covs, volume, volume1, npix,
+                       H2, W2, radius);
+  }
+  return launch_status();
+}
+
+int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* volume, const float* volume1_grad,
+                          float* means_grad, float* covs_grad, int E, int H1, int W1, int H2, int W2, int radius,
+                          void* stream) {
+  using namespace lgu;
+  if (!means || !covs || !volume || !volume1_grad || !means_grad || !covs_grad) return LGU_E_BADARG;
+  if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  const size_t npix = (size_t)E * H1 * W1;
+  const unsigned grid = (unsigned)((npix + 3) / 4);
+  hipLaunchKernelGGL(gaussmask_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), means,
+                     covs, volume, volume1_grad, means_grad, covs_grad, npix, H2, W2, radius);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+// lowmem.hip — on-the-fly correlation sampling from feature maps (no stored volume).
+//
+// Replaces (reference, relative to /root/reference):
+//   offersample_LGS/lowMem_defSample.cu:27-134   lowMem_defSample_kernel  (host :137-168)
+//   src/altcorr_kernel.cu:27-149                 altcorr_forward_kernel   (host :290-319)
+//   src/altcorr_kernel.cu:152-286                altcorr_backward_kernel  (host :321-356)
+//
+// The reference uses (4,8) = 32-thread blocks (half a wave64), one thread per pixel, and a
+// 32-channel LDS round trip with no reuse.  Here ONE WAVE serves one pixel with LANES =
+// CHANNELS: lane c holds fmap1[pixel][c + 64q] in registers; for every tap the four corner
+// rows of fmap2 (C contiguous floats each) are read with fully coalesced 256-byte loads,
+// blended per channel, multiplied and reduced across the wave.  fmap2 of one edge is a few
+// MB and every pixel of that edge re-reads a moving window of it, so these loads are
+// L2-served; a workgroup = 4 waves x 4 pixels = 16 adjacent pixels parks its results in an
+// LDS [tap][pixel] tile and writes 64-byte coalesced segments.
+// Summation over channels is a per-lane partial + wave tree instead of the reference's
+// sequential 32-channel chunks: equal up to fp32 rounding (tests: 1e-5).
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+constexpr int LM_TP = 16, LM_WAVES = 4, LM_PPW = LM_TP / LM_WAVES;
+constexpr int LM_PITCH = LM_TP + 1;
+constexpr int LM_MAXQ = 8;  // channels per lane: C <= 512
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  // row-local xor/mirror steps on the VALU, then one cross-row butterfly
+#define LGU_SUM_STEP(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+  LGU_SUM_STEP(0xB1)
+  LGU_SUM_STEP(0x4E)
+  LGU_SUM_STEP(0x141)
+  LGU_SUM_STEP(0x140)
+#undef LGU_SUM_STEP
+  v += __shfl_xor(v, 16, kWave);
+  v += __shfl_xor(v, 32, kWave);
+  return v;
+}
+
+// ---- lowMem_defSample ---------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(LM_WAVES * kWave) void lowmem_kernel(const float* __restrict__ fmap1,
+                                                                  const float* __restrict__ fmap2,
+                                                                  const float* __restrict__ coords, float* offset,
+                                                                  float* __restrict__ corr, int B, int S, int H1,
+                                                                  int W1, int H2, int W2, int C, int r,
+                                                                  int tiles_per_row) {
+  extern __shared__ float outst[];  // [S*nt][LM_PITCH]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rd = 2 * r + 1, nt = rd * rd;
+  int bid = blockIdx.x;
+  const int tile = bid % tiles_per_row;
+  bid /= tiles_per_row;
+  const int h1 = bid % H1;
+  const int b = bid / H1;
+  const int xbase = tile * LM_TP;
+  const size_t HW1 = (size_t)H1 * W1;
+  const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+
+  for (int k = 0; k < LM_PPW; k++) {
+    const int w1 = xbase + w * LM_PPW + k;
+    if (w1 >= W1) break;  // wave-uniform
+    float f1[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int c = q * kWave + lane;
+      f1[q] = c < C ? fmap1[(((size_t)b * H1 + h1) * W1 + w1) * C + c] : 0.0f;
+    }
+    for (int n = 0; n < S; n++) {
+      const float cx = coords[((((size_t)b * S + n) * H1 + h1) * W1 + w1) * 2 + 0];
+      const float cy = coords[((((size_t)b * S + n) * H1 + h1) * W1 + w1) * 2 + 1];
+      // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83), centre forced to 0
+      float* obase = offset + ((size_t)(b * n) * HW1 + (size_t)h1 * W1 + w1) * nt * 2;
+      float mine = 0.0f;  // lane t keeps tap t's result
+      for (int t0 = 0; t0 < nt; t0 += kWave) {
+        float2 myoff = make_float2(0.f, 0.f);
+        const int tl = t0 + lane;
+        if (tl < nt) {
+          if (tl == r * rd + r) *reinterpret_cast<float2*>(obase + tl * 2) = make_float2(0.f, 0.f);
+          else myoff = *reinterpret_cast<const float2*>(obase + tl * 2);
+        }
+        const int tend = (nt - t0) < kWave ? (nt - t0) : kWave;
+        for (int tt = 0; tt < tend; tt++) {
+          const int t = t0 + tt;
+          const int ix = t / rd, iy = t - ix * rd;  // offset/out index [ix][iy]
+          const float xs = cx + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myoff.x), tt));
+          const float ys = cy + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myoff.y), tt));
+          const float fxs = floorf(xs), fys = floorf(ys);
+          const float dx = xs - fxs, dy = ys - fys;  // :87-88
+          const int h2 = (int)fys - r + iy, w2 = (int)fxs - r + ix;
+          const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
+          const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
+          const float w11 = (1.0f - dy) * (1.0f - dx), w21 = (1.0f - dy) * dx;
+          const float w12 = dy * (1.0f - dx), w22 = dy * dx;
+          float acc = 0.0f;
+          if (b11 || b21 || b12 || b22) {  // wave-uniform
+            const float* p11 = F2 + ((size_t)h2 * W2 + w2) * C;
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const int c = q * kWave + lane;
+              const bool cv = c < C;
+              const float q11 = (b11 && cv) ? p11[c] : 0.0f;  // per-corner zero padding :102-112
+              const float q21 = (b21 && cv) ? p11[C + c] : 0.0f;
+              const float q12 = (b12 && cv) ? p11[(size_t)W2 * C + c] : 0.0f;
+              const float q22 = (b22 && cv) ? p11[(size_t)W2 * C + C + c] : 0.0f;
+              const float f2 = q11 * w11 + q21 * w21 + q12 * w12 + q22 * w22;  // :114-117
+              acc += f1[q] * f2;
+            }
+            acc = wave_sum_dpp(acc);
+          }
+          if (lane == tt) mine = acc;
+        }
+        if (tl < nt) outst[(n * nt + tl) * LM_PITCH + (w * LM_PPW + k)] = mine;
+      }
+    }
+  }
+  __syncthreads();
+  const int nout = S * nt * LM_TP;
+  for (int idx = threadIdx.x; idx < nout; idx += LM_WAVES * kWave) {
+    const int c = idx >> 4, pc = idx & (LM_TP - 1);
+    const int n = c / nt, t = c - n * nt;
+    if (xbase + pc < W1)
+      corr[((((size_t)b * S + n) * nt + t) * H1 + h1) * W1 + xbase + pc] = outst[c * LM_PITCH + pc];
+  }
+}
+
+// ---- altcorr forward ------------------------------------------------------------------
+// lattice (rd+1)^2 <= 64 points, one per lane after the reduction; output channel
+// ch = ix*rd + iy gathers its four lattice neighbours in the reference's order
+// (altcorr_kernel.cu:102-142: se of (iy,ix), sw of (iy,ix+1), ne of (iy+1,ix), nw of (iy+1,ix+1)).
+template <int Q>
+__global__ __launch_bounds__(LM_WAVES * kWave) void altcorr_fwd_kernel(const float* __restrict__ fmap1,
+                                                                       const float* __restrict__ fmap2,
+                                                                       const float* __restrict__ coords,
+                                                                       float* __restrict__ corr, int B, int S, int H1,
+                                                                       int W1, int H2, int W2, int C, int r,
+                                                                       int tiles_per_row) {
+  extern __shared__ float outst[];  // [S*nt][LM_PITCH]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rd = 2 * r + 1, nt = rd * rd, rl = rd + 1, nl = rl * rl;
+  int bid = blockIdx.x;
+  const int tile = bid % tiles_per_row;
+  bid /= tiles_per_row;
+  const int h1 = bid % H1;
+  const int b = bid / H1;
+  const int xbase = tile * LM_TP;
+  const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+
+  for (int k = 0; k < LM_PPW; k++) {
+    const int w1 = xbase + w * LM_PPW + k;
+    if (w1 >= W1) break;
+    float f1[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int c = q * kWave + lane;
+      f1[q] = c < C ? fmap1[(((size_t)b * H1 + h1) * W1 + w1) * C + c] : 0.0f;
+    }
+    for (int n = 0; n < S; n++) {
+      const float xs = coords[((((size_t)b * S + n) * H1 + h1) * W1 + w1) * 2 + 0];
+      const float ys = coords[((((size_t)b * S + n) * H1 + h1) * W1 + w1) * 2 + 1];
+      const float fxs = floorf(xs), fys = floorf(ys);
+      const float dx = xs - fxs, dy = ys - fys;
+      float mine = 0.0f;  // lane (iy*rl + ix) keeps lattice sum s[iy][ix]
+      for (int li = 0; li < nl; li++) {
+        const int iy = li / rl, ix = li - iy * rl;
+        const int h2 = (int)fys - r + iy, w2 = (int)fxs - r + ix;
+        float acc = 0.0f;
+        if (in_bounds(h2, w2, H2, W2)) {
+          const float* p2 = F2 + ((size_t)h2 * W2 + w2) * C;
+#pragma unroll
+          for (int q = 0; q < Q; q++) {
+            const int c = q * kWave + lane;
+            if (c < C) acc += f1[q] * p2[c];
+          }
+          acc = wave_sum_dpp(acc);
+        }
+        if (lane == li) mine = acc;
+      }
+      // output lane = channel ch = ox*rd + oy  (ox along x, oy along y)
+      const int ch = lane < nt ? lane : 0;
+      const int ox = ch / rd, oy = ch - ox * rd;
+      const float s_se = __shfl(mine, oy * rl + ox, kWave);
+      const float s_sw = __shfl(mine, oy * rl + ox + 1, kWave);
+      const float s_ne = __shfl(mine, (oy + 1) * rl + ox, kWave);
+      const float s_nw = __shfl(mine, (oy + 1) * rl + ox + 1, kWave);
+      float o = 0.0f;
+      o += s_se * ((1 - dy) * (1 - dx));  // :115,141
+      o += s_sw * ((1 - dy) * dx);        // :114,138
+      o += s_ne * (dy * (1 - dx));        // :113,135
+      o += s_nw * (dy * dx);              // :112,132
+      if (lane < nt) outst[(n * nt + lane) * LM_PITCH + (w * LM_PPW + k)] = o;
+    }
+  }
+  __syncthreads();
+  const int nout = S * nt * LM_TP;
+  for (int idx = threadIdx.x; idx < nout; idx += LM_WAVES * kWave) {
+    const int c = idx >> 4, pc = idx & (LM_TP - 1);
+    const int n = c / nt, t = c - n * nt;
+    if (xbase + pc < W1)
+      corr[((((size_t)b * S + n) * nt + t) * H1 + h1) * W1 + xbase + pc] = outst[c * LM_PITCH + pc];
+  }
+}
+
+// ---- altcorr backward -----------------------------------------------------------------
+template <int Q>
+__global__ __launch_bounds__(LM_WAVES * kWave) void altcorr_bwd_kernel(const float* __restrict__ fmap1,
+                                                                       const float* __restrict__ fmap2,
+                                                                       const float* __restrict__ coords,
+                                                                       const float* __restrict__ corr_grad,
+                                                                       float* __restrict__ fmap1_grad,
+                                                                       float* fmap2_grad, int B, int S, int H1, int W1,
+                                                                       int H2, int W2, int C, int r) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const size_t HW1 = (size_t)H1 * W1;
+  const size_t pix = (size_t)blockIdx.x * LM_WAVES + (threadIdx.x >> 6);
+  if (pix >= (size_t)B * HW1) return;
+  const int b = (int)(pix / HW1);
+  const size_t yx = pix - (size_t)b * HW1;
+  const int rd = 2 * r + 1, rl = rd + 1, nl = rl * rl;
+  const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  float* F2G = fmap2_grad + (size_t)b * H2 * W2 * C;
+  float f1[Q], f1g[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int c = q * kWave + lane;
+    f1[q] = c < C ? fmap1[pix * C + c] : 0.0f;
+    f1g[q] = 0.0f;
+  }
+  for (int n = 0; n < S; n++) {
+    const float xs = coords[(((size_t)b * S + n) * HW1 + yx) * 2 + 0];
+    const float ys = coords[(((size_t)b * S + n) * HW1 + yx) * 2 + 1];
+    const float fxs = floorf(xs), fys = floorf(ys);
+    const float dx = xs - fxs, dy = ys - fys;
+    const float* gp = corr_grad + (((size_t)b * S + n) * rd * rd) * HW1 + yx;
+    // lane li = iy*rl + ix forms g of its lattice point (altcorr_kernel.cu:238-250)
+    float gl = 0.0f;
+    if (lane < nl) {
+      const int iy = lane / rl, ix = lane - iy * rl;
+      if (iy > 0 && ix > 0) gl += gp[(size_t)((iy - 1) + rd * (ix - 1)) * HW1] * dy * dx;
+      if (iy > 0 && ix < rd) gl += gp[(size_t)((iy - 1) + rd * ix) * HW1] * dy * (1 - dx);
+      if (iy < rd && ix > 0) gl += gp[(size_t)(iy + rd * (ix - 1)) * HW1] * (1 - dy) * dx;
+      if (iy < rd && ix < rd) gl += gp[(size_t)(iy + rd * ix) * HW1] * (1 - dy) * (1 - dx);
+    }
+    for (int li = 0; li < nl; li++) {
+      const int iy = li / rl, ix = li - iy * rl;
+      const int h2 = (int)fys - r + iy, w2 = (int)fxs - r + ix;
+      if (!in_bounds(h2, w2, H2, W2)) continue;  // f2 = 0 and no scatter (:229-232,262-267)
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), li));
+      const float* p2 = F2 + ((size_t)h2 * W2 + w2) * C;
+      float* p2g = F2G + ((size_t)h2 * W2 + w2) * C;
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int c = q * kWave + lane;
+        if (c < C) {
+          f1g[q] += g * p2[c];             // :253
+          atomicAdd(p2g + c, g * f1[q]);   // :254,267 — 256 contiguous bytes per wave instruction
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int c = q * kWave + lane;
+    if (c < C) fmap1_grad[pix * C + c] = f1g[q];
+  }
+}
+
+static int check_fmap_args(const void* a, const void* b, const void* c, const void* d, int B, int S, int H1, int W1,
+                           int H2, int W2, int C, int radius) {
+  if (!a || !b || !c || !d) return LGU_E_BADARG;
+  if (B < 0 || S < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || radius < 0 || radius > LGU_MAX_RADIUS)
+    return LGU_E_BADARG;
+  if (C % 32 != 0 || C > LM_MAXQ * kWave) return LGU_E_UNSUPPORTED;  // reference needs C % 32 == 0 too
+  return LGU_OK;
+}
+
+#define LGU_DISPATCH_Q(C, CALL)                      \
+  do {                                               \
+    const int q_ = ((C) + kWave - 1) / kWave;        \
+    if (q_ <= 1) { CALL(1); }                        \
+    else if (q_ <= 2) { CALL(2); }                   \
+    else if (q_ <= 4) { CALL(4); }                   \
+    else { CALL(8); }                                \
+  } while (0)
+
+}  // namespace lgu
+
+extern "C" {
+
+int lgu_lowmem_defsample_fwd_f32(const float* fmap1, const float* fmap2, const float* coords, float* offset,
+                                 float* corr, int B, int S, int H1, int W1, int H2, int W2, int C, int NO, int radius,
+                                 void* stream) {
+  using namespace lgu;
+  int rc = check_fmap_args(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius);
+  if (rc != LGU_OK) return rc;
+  if (!offset || (long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
+  if (B == 0) return LGU_OK;
+  const int nt = (2 * radius + 1) * (2 * radius + 1);
+  const int tiles = (W1 + LM_TP - 1) / LM_TP;
+  const size_t lds = sizeof(float) * (size_t)S * nt * LM_PITCH;
+  if (lds > 64 * 1024) return LGU_E_UNSUPPORTED;
+  const unsigned grid = (unsigned)((size_t)B * H1 * tiles);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define CALL(QV)                                                                                                     \
+  hipLaunchKernelGGL(lowmem_kernel<QV>, dim3(grid), dim3(LM_WAVES * kWave), lds, st, fmap1, fmap2, coords, offset, \
+                     corr, B, S, H1, W1, H2, W2, C, radius, tiles)
+  LGU_DISPATCH_Q(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int lgu_altcorr_fwd_f32(const float* fmap1, const float* fmap2, const float* coords, float* corr, int B, int S, int H1,
+                        int W1, int H2, int W2, int C, int radius, void* stream) {
+  using namespace lgu;
+  int rc = check_fmap_args(fmap1, fmap2, coords, corr, B, S, H1, W1, H2, W2, C, radius);
+  if (rc != LGU_OK) return rc;
+  if (radius > 3) return LGU_E_UNSUPPORTED;  // lattice (rd+1)^2 must fit one wave
+  if (B == 0) return LGU_OK;
+  const int nt = (2 * radius + 1) * (2 * radius + 1);
+  const int tiles = (W1 + LM_TP - 1) / LM_TP;
+  const size_t lds = sizeof(float) * (size_t)S * nt * LM_PITCH;
+  if (lds > 64 * 1024) return LGU_E_UNSUPPORTED;
+  const unsigned grid = (unsigned)((size_t)B * H1 * tiles);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define CALL(QV)                                                                                                  \
+  hipLaunchKernelGGL(altcorr_fwd_kernel<QV>, dim3(grid), dim3(LM_WAVES * kWave), lds, st, fmap1, fmap2, coords, \
+                     corr, B, S, H1, W1, H2, W2, C, radius, tiles)
+  LGU_DISPATCH_Q(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int lgu_altcorr_bwd_f32(const float* fmap1, const float* fmap2, const float* coords, const float* corr_grad,
+                        float* fmap1_grad, float* fmap2_grad, int B, int S, int H1, int W1, int H2, int W2, int C,
+                        int radius, void* stream) {
+  using namespace lgu;
+  int rc = check_fmap_args(fmap1, fmap2, coords, corr_grad, B, S, H1, W1, H2, W2, C, radius);
+  if (rc != LGU_OK) return rc;
+  if (!fmap1_grad || !fmap2_grad) return LGU_E_BADARG;
+  if (radius > 3) return LGU_E_UNSUPPORTED;
+  if (B == 0) return LGU_OK;
+  const size_t npix = (size_t)B * H1 * W1;
+  const unsigned grid = (unsigned)((npix + LM_WAVES - 1) / LM_WAVES);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define CALL(QV)                                                                                                \
+  hipLaunchKernelGGL(altcorr_bwd_kernel<QV>, dim3(grid), dim3(LM_WAVES * kWave), 0, st, fmap1, fmap2, coords, \
+                     corr_grad, fmap1_grad, fmap2_grad, B, S, H1, W1, H2, W2, C, radius)
+  LGU_DISPATCH_Q(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+}  // extern "C"

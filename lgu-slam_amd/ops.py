@@ -1,0 +1,187 @@
+"""Operator layer: the reference's Python-visible operator signatures on top of the C ABI.
+
+Each function mirrors one pybind11 entry of the reference (names, positional arguments,
+list-of-tensors return, in-place side effects, error text):
+  defCorrSample.*            offersample_LGS/droid.cpp:53-147
+  droid_backends.altcorr_*   src/droid.cpp:193-217,246-247
+Tensors must live on a HIP device ("cuda" in PyTorch-ROCm) — there is no CPU path — and
+be float32 (what every reference call site passes: corr.py:30-31,64,202,209;
+gaussianMask_cuda.py:11-12).  Kernels are enqueued on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_vp = ctypes.c_void_p
+
+
+def _check(t, name, dtype=torch.float32):
+    # reference: TORCH_CHECK(x.is_contiguous(), #x " must be contiguous")  (droid.cpp:48-49)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a HIP device tensor: lgu_slam_amd has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("expected scalar type Float but found %s (%s)" % (str(t.dtype).replace("torch.", ""), name))
+
+
+def _stream(t):
+    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return _vp(t.data_ptr())
+
+
+def defCorr_index_forward(volume, coords, offset, radius):
+    _check(volume, "volume"); _check(coords, "coords"); _check(offset, "offset")
+    E, H1, W1, H2, W2 = volume.shape
+    rd = 2 * radius + 1
+    if tuple(coords.shape) != (E, 2, H1, W1) or offset.numel() != E * H1 * W1 * rd * rd * 2:
+        raise RuntimeError("defCorr_index_forward: shape mismatch between volume, coords and offset")
+    corr = torch.empty((E, rd, rd, H1, W1), dtype=volume.dtype, device=volume.device)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_defcorr_fwd_f32(_ptr(volume), _ptr(coords), _ptr(offset), _ptr(corr),
+                                             E, H1, W1, H2, W2, radius, _stream(volume))
+    _lib.check(rc, "defCorr_index_forward")
+    return [corr]
+
+
+def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
+    _check(volume, "volume"); _check(coords, "coords"); _check(offset, "offset"); _check(corr_grad, "corr_grad")
+    E, H1, W1, H2, W2 = volume.shape
+    volume_grad = torch.zeros_like(volume)
+    offset_grad = torch.empty_like(offset)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_defcorr_bwd_f32(_ptr(volume), _ptr(coords), _ptr(offset), _ptr(corr_grad),
+                                             _ptr(volume_grad), _ptr(offset_grad), E, H1, W1, H2, W2, radius,
+                                             _stream(volume))
+    _lib.check(rc, "defCorr_index_backward")
+    return [volume_grad, offset_grad]
+
+
+def corr_index_forward(volume, coords, radius):
+    _check(volume, "volume"); _check(coords, "coords")
+    E, H1, W1, H2, W2 = volume.shape
+    rd = 2 * radius + 1
+    if tuple(coords.shape) != (E, 2, H1, W1):
+        raise RuntimeError("corr_index_forward: coords must be (E,2,H1,W1)")
+    corr = torch.empty((E, rd, rd, H1, W1), dtype=volume.dtype, device=volume.device)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_corridx_fwd_f32(_ptr(volume), _ptr(coords), _ptr(corr), E, H1, W1, H2, W2, radius,
+                                             _stream(volume))
+    _lib.check(rc, "corr_index_forward")
+    return [corr]
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    _check(volume, "volume"); _check(coords, "coords"); _check(corr_grad, "corr_grad")
+    E, H1, W1, H2, W2 = volume.shape
+    volume_grad = torch.zeros_like(volume)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_corridx_bwd_f32(_ptr(volume), _ptr(coords), _ptr(corr_grad), _ptr(volume_grad),
+                                             E, H1, W1, H2, W2, radius, _stream(volume))
+    _lib.check(rc, "corr_index_backward")
+    return [volume_grad]
+
+
+def gaussianMask(means, covs, volume, radius):
+    _check(volume, "volume"); _check(means, "means"); _check(covs, "covs")
+    E, H1, W1, H2, W2 = volume.shape
+    volume1 = torch.empty_like(volume)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_gaussmask_fwd_f32(_ptr(means), _ptr(covs), _ptr(volume), _ptr(volume1),
+                                               E, H1, W1, H2, W2, radius, _stream(volume))
+    _lib.check(rc, "gaussianMask")
+    return [volume1]
+
+
+def gaussianMask_backward(means, covs, volume, volume_grad, radius):
+    _check(volume, "volume"); _check(means, "means"); _check(covs, "covs"); _check(volume_grad, "volume_grad")
+    E, H1, W1, H2, W2 = volume.shape
+    means_grad = torch.empty_like(means)
+    covs_grad = torch.empty_like(covs)
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_gaussmask_bwd_f32(_ptr(means), _ptr(covs), _ptr(volume), _ptr(volume_grad),
+                                               _ptr(means_grad), _ptr(covs_grad), E, H1, W1, H2, W2, radius,
+                                               _stream(volume))
+    _lib.check(rc, "gaussianMask_backward")
+    return [means_grad, covs_grad]
+
+
+def lowMem_defSample(fmap1, fmap2, coords, offset, radius):
+    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords"); _check(offset, "offset")
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    rd = 2 * radius + 1
+    corr = torch.empty((B, S, rd, rd, H1, W1), dtype=fmap1.dtype, device=fmap1.device)
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_lowmem_defsample_fwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(offset), _ptr(corr),
+                                                      B, S, H1, W1, H2, W2, C, offset.shape[0], radius,
+                                                      _stream(fmap1))
+    _lib.check(rc, "lowMem_defSample")
+    return [corr]
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords")
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    rd = 2 * radius + 1
+    corr = torch.empty((B, S, rd * rd, H1, W1), dtype=fmap1.dtype, device=fmap1.device)
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_altcorr_fwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr),
+                                             B, S, H1, W1, H2, W2, C, radius, _stream(fmap1))
+    _lib.check(rc, "altcorr_forward")
+    return [corr]
+
+
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
+    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords"); _check(corr_grad, "corr_grad")
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    fmap1_grad = torch.empty_like(fmap1)
+    fmap2_grad = torch.zeros_like(fmap2)
+    coords_grad = torch.zeros_like(coords)  # allocated, never written by the reference (altcorr_kernel.cu:336)
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_altcorr_bwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr_grad),
+                                             _ptr(fmap1_grad), _ptr(fmap2_grad), B, S, H1, W1, H2, W2, C, radius,
+                                             _stream(fmap1))
+    _lib.check(rc, "altcorr_backward")
+    return [fmap1_grad, fmap2_grad, coords_grad]
+
+
+def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None):
+    """Fused CorrBlock.__call__ body (reference droid_slam/modules/corr.py:88-109): all
+    pyramid levels in ONE launch, written straight into the concatenated tensor.
+
+    volumes: list of L tensors (E,H1,W1,H2l,W2l); coords (E,2,H1,W1) in level-0 units
+    (each level samples at coords / 2^l); offsets: list of L tensors (E,H1,W1,rd,rd,2)
+    or None for a structurally-zero level.  Offsets are modified in place (centre zeroing).
+    Returns (E, L*rd*rd, H1, W1).
+    """
+    L = len(volumes)
+    if len(offsets) != L:
+        raise RuntimeError("defcorr_pyramid_forward: need one offset entry (tensor or None) per level")
+    _check(coords, "coords")
+    for l, v in enumerate(volumes):
+        _check(v, "volume[%d]" % l)
+        if offsets[l] is not None:
+            _check(offsets[l], "offset[%d]" % l)
+    E, H1, W1 = volumes[0].shape[:3]
+    rd = 2 * radius + 1
+    if out is None:
+        out = torch.empty((E, L * rd * rd, H1, W1), dtype=torch.float32, device=coords.device)
+    else:
+        _check(out, "out")
+    vp = (_vp * L)(*[v.data_ptr() for v in volumes])
+    op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
+    h2 = (ctypes.c_int * L)(*[v.shape[3] for v in volumes])
+    w2 = (ctypes.c_int * L)(*[v.shape[4] for v in volumes])
+    with torch.cuda.device(coords.device):
+        rc = _lib.load().lgu_defcorr_pyramid_fwd_f32(vp, _ptr(coords), op, _ptr(out), L, E, H1, W1, h2, w2, radius,
+                                                     1 if probe else 0, _stream(coords))
+    _lib.check(rc, "defcorr_pyramid_forward")
+    return out

@@ -1,0 +1,264 @@
+"""GPU parity: every C-ABI entry point (through the Python operator layer, which is a thin
+ctypes pass-through) against the CPU oracle on identical seeded inputs.
+
+Tolerances: north_star states 1e-5 fp32.  The forward samplers share the oracle's
+evaluation order and are held to 1e-6 (they are expected to be bit-exact); ops whose
+reduction order differs (tree sums over channels / taps, atomics) are held to 1e-5
+absolute at the magnitudes of these inputs, or 1e-5 relative to the output scale where
+the outputs are large (gradients).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import inputs
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native(lgu):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    # the HIP library must be the thing under test: fail loudly if it is absent
+    assert os.path.exists(lgu._lib.so_path()), "liblgu_corr.so missing — run __graft_entry__.build()"
+    lgu._lib.load()
+
+
+def set_variant(v):
+    os.environ["LGU_DEFCORR_VARIANT"] = str(v)
+
+
+@pytest.fixture(autouse=True)
+def _reset_variant():
+    yield
+    os.environ.pop("LGU_DEFCORR_VARIANT", None)
+
+
+def run_pyramid(lgu, case, radius, variant=0):
+    set_variant(variant)
+    vols = [dev(v) for v in case["volumes"]]
+    offs = [dev(o) if o is not None else None for o in case["offsets"]]
+    out = lgu.ops.defcorr_pyramid_forward(vols, dev(case["coords"]), offs, radius)
+    torch.cuda.synchronize()
+    return host(out), [host(o) if o is not None else None for o in offs]
+
+
+def oracle_pyramid(O, case, radius):
+    offs = [o.copy() if o is not None else None for o in case["offsets"]]
+    out = O.defcorr_pyramid_forward(case["volumes"], case["coords"], offs, radius)
+    return out, offs
+
+
+PYR_CASES = {
+    # name: (seed, E, H1, W1, L, radius, sigma, off_scale, dense)
+    "tiny": (1, 2, 12, 16, 3, 3, 3.0, 4.0, False),
+    "cfg2_shape": (2, 2, 48, 64, 4, 3, 3.0, 4.0, False),
+    "border_stress": (3, 2, 24, 32, 3, 3, 20.0, 4.0, False),
+    "dense_offsets": (4, 1, 24, 32, 3, 3, 3.0, 4.0, True),
+    "huge_offsets_direct_path": (5, 1, 48, 64, 2, 3, 3.0, 14.0, True),
+    "ragged_width": (6, 2, 30, 40, 2, 3, 3.0, 4.0, False),   # W1 = 40 = 2.5 tiles; level 1 is 15x20
+    "radius1": (7, 2, 24, 32, 2, 1, 3.0, 2.0, True),
+    "radius2": (8, 1, 24, 32, 2, 2, 3.0, 3.0, True),
+    "generic_w2_not_mult4": (9, 1, 20, 24, 3, 3, 3.0, 4.0, False),  # level 2 is 5x6
+}
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("name", list(PYR_CASES))
+def test_defcorr_pyramid_matches_oracle(lgu, oracle, name, variant):
+    seed, E, H1, W1, L, radius, sigma, osc, dense = PYR_CASES[name]
+    case = inputs.pyramid_case(seed, E, H1, W1, L, radius, sigma, osc, dense)
+    want, want_offs = oracle_pyramid(oracle, case, radius)
+    got, got_offs = run_pyramid(lgu, case, radius, variant)
+    err = np.abs(got - want).max()
+    assert err <= 1e-6, "%s variant %d: max abs err %g" % (name, variant, err)
+    # in-place side effect: centre offsets zeroed, everything else untouched
+    for a, b in zip(got_offs, want_offs):
+        if a is not None:
+            assert np.array_equal(a, b)
+
+
+def test_defcorr_single_level_and_plain_identity(lgu, oracle):
+    case = inputs.pyramid_case(11, 2, 24, 32, 1, 3, 3.0, 4.0, True)
+    v, c, off = case["volumes"][0], case["coords"], case["offsets"][0]
+    o_ref = off.copy()
+    want, = oracle.defCorr_index_forward(v, c, o_ref, 3)
+    o_dev = dev(off)
+    got, = lgu.ops.defCorr_index_forward(dev(v), dev(c), o_dev, 3)
+    assert isinstance(got, torch.Tensor) and got.shape == (2, 7, 7, 24, 32)
+    assert np.abs(host(got) - want).max() <= 1e-6
+    assert np.array_equal(host(o_dev), o_ref)
+    # defCorr(offset = 0) == corr_index (reference identity): bit-exact
+    z = torch.zeros_like(o_dev)
+    a, = lgu.ops.defCorr_index_forward(dev(v), dev(c), z, 3)
+    b, = lgu.ops.corr_index_forward(dev(v), dev(c), 3)
+    assert torch.equal(a, b)
+    want_b, = oracle.corr_index_forward(v, c, 3)
+    assert np.abs(host(b) - want_b).max() <= 1e-6
+
+
+def test_probe_shape_r1_level1(lgu, oracle):
+    # the call CorrBlock makes for the uncertainty probe (corr.py:94): level-1 volume, coords/2, r=1
+    rng = np.random.default_rng(12)
+    v = rng.standard_normal((3, 48, 64, 24, 32)).astype(np.float32)
+    c = inputs.grid_coords(rng, 3, 48, 64, 3.0) / 2
+    want, = oracle.corr_index_forward(v, c, 1)
+    got, = lgu.ops.corr_index_forward(dev(v), dev(c), 1)
+    assert got.shape == (3, 3, 3, 48, 64)
+    assert np.abs(host(got) - want).max() <= 1e-6
+
+
+@pytest.mark.parametrize("radius,sigma", [(3, 3.0), (3, 15.0), (1, 3.0)])
+def test_defcorr_backward(lgu, oracle, radius, sigma):
+    rng = np.random.default_rng(20 + radius)
+    E, H1, W1, H2, W2 = 2, 12, 16, 12, 16
+    rd = 2 * radius + 1
+    v = rng.standard_normal((E, H1, W1, H2, W2)).astype(np.float32)
+    c = inputs.grid_coords(rng, E, H1, W1, sigma)
+    off = (4 * np.tanh(rng.standard_normal((E, H1, W1, rd, rd, 2)))).astype(np.float32)
+    g = rng.standard_normal((E, rd, rd, H1, W1)).astype(np.float32)
+    o_ref = off.copy()
+    vg_w, og_w = oracle.defCorr_index_backward(v, c, o_ref, g, radius)
+    o_dev = dev(off)
+    vg, og = lgu.ops.defCorr_index_backward(dev(v), dev(c), o_dev, dev(g), radius)
+    assert np.abs(host(og) - og_w).max() <= 1e-5 * max(1.0, np.abs(og_w).max())
+    assert np.abs(host(vg) - vg_w).max() <= 1e-5 * max(1.0, np.abs(vg_w).max())
+    assert np.array_equal(host(o_dev), o_ref)
+    # plain sampler backward
+    vg2_w, = oracle.corr_index_backward(v, c, g, radius)
+    vg2, = lgu.ops.corr_index_backward(dev(v), dev(c), dev(g), radius)
+    assert np.abs(host(vg2) - vg2_w).max() <= 1e-5 * max(1.0, np.abs(vg2_w).max())
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16, 12, 16), (1, 48, 64, 48, 64), (1, 10, 10, 9, 10)])
+def test_gaussian_mask_forward_backward(lgu, oracle, shape):
+    E, H1, W1, H2, W2 = shape
+    rng = np.random.default_rng(30 + H1)
+    v = rng.standard_normal(shape).astype(np.float32)
+    ys, xs = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
+    means = (np.stack([xs, ys], -1)[None].repeat(E, 0) + rng.standard_normal((E, H1, W1, 2)) * 2).astype(np.float32)
+    covs = (rng.uniform(0.05, 5.05, (E, H1, W1, 2))).astype(np.float32)
+    want, = oracle.gaussianMask(means, covs, v, 4)
+    got, = lgu.ops.gaussianMask(dev(means), dev(covs), dev(v), 4)
+    # expf differs by <= 2 ulp between libm and the device: relative 2.4e-7 of values <= ~15
+    assert np.abs(host(got) - want).max() <= 1e-5
+    assert np.array_equal(host(got) == 0, want == 0)  # identical support (zero outside the window)
+    g = rng.standard_normal(shape).astype(np.float32)
+    mg_w, cg_w = oracle.gaussianMask_backward(means, covs, v, g, 4)
+    mg, cg = lgu.ops.gaussianMask_backward(dev(means), dev(covs), dev(v), dev(g), 4)
+    assert np.abs(host(mg) - mg_w).max() <= 1e-5 * max(1.0, np.abs(mg_w).max())
+    assert np.abs(host(cg) - cg_w).max() <= 1e-5 * max(1.0, np.abs(cg_w).max())
+
+
+LOWMEM_CASES = [
+    # B, S, H1, W1, H2, W2, C, radius, sigma, scale
+    (3, 1, 12, 16, 12, 16, 128, 3, 3.0, 1.0),
+    (2, 1, 12, 16, 6, 8, 128, 3, 3.0, 0.5),
+    (2, 1, 15, 20, 7, 10, 64, 3, 6.0, 0.5),     # ragged: W1 = 20, odd H2/W2 as in 60x80 level 3
+    (1, 2, 8, 16, 8, 16, 32, 1, 3.0, 1.0),      # S = 2 uses offset[b*n]
+]
+
+
+@pytest.mark.parametrize("cfg", LOWMEM_CASES)
+def test_lowmem_defsample(lgu, oracle, cfg):
+    B, S, H1, W1, H2, W2, C, radius, sigma, scale = cfg
+    case = inputs.fmap_case(40 + H2, B, S, H1, W1, H2, W2, C, radius, sigma, scale)
+    o_ref = case["offset"].copy()
+    want, = oracle.lowMem_defSample(case["fmap1"], case["fmap2"], case["coords"], o_ref, radius)
+    o_dev = dev(case["offset"])
+    got, = lgu.ops.lowMem_defSample(dev(case["fmap1"]), dev(case["fmap2"]), dev(case["coords"]), o_dev, radius)
+    assert got.shape == want.shape
+    assert np.abs(host(got) - want).max() <= 1e-5
+    assert np.array_equal(host(o_dev), o_ref)  # edge-0 centre zeroed (b*n indexing), rest untouched
+
+
+@pytest.mark.parametrize("cfg", [(3, 1, 12, 16, 6, 8, 128, 1, 3.0, 0.5), (2, 2, 8, 16, 8, 16, 64, 3, 5.0, 1.0),
+                                 (1, 1, 15, 20, 7, 10, 128, 1, 8.0, 0.5)])
+def test_altcorr_forward_backward(lgu, oracle, cfg):
+    B, S, H1, W1, H2, W2, C, radius, sigma, scale = cfg
+    case = inputs.fmap_case(50 + H2, B, S, H1, W1, H2, W2, C, radius, sigma, scale)
+    want, = oracle.altcorr_forward(case["fmap1"], case["fmap2"], case["coords"], radius)
+    got, = lgu.ops.altcorr_forward(dev(case["fmap1"]), dev(case["fmap2"]), dev(case["coords"]), radius)
+    assert got.shape == want.shape
+    assert np.abs(host(got) - want).max() <= 1e-5
+    rng = np.random.default_rng(60)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    f1g_w, f2g_w, cg_w = oracle.altcorr_backward(case["fmap1"], case["fmap2"], case["coords"], g, radius)
+    f1g, f2g, cg = lgu.ops.altcorr_backward(dev(case["fmap1"]), dev(case["fmap2"]), dev(case["coords"]), dev(g), radius)
+    assert np.abs(host(f1g) - f1g_w).max() <= 1e-5 * max(1.0, np.abs(f1g_w).max())
+    assert np.abs(host(f2g) - f2g_w).max() <= 1e-5 * max(1.0, np.abs(f2g_w).max())
+    assert not host(cg).any()
+
+
+def test_full_size_properties(lgu):
+    """BASELINE cfg2 size (E=20, 48x64, L=4, r=3): size-independent properties instead of
+    a full oracle run — linearity in the volume, zero-offset == plain sampler, variant
+    agreement, idempotence of the in-place centre zeroing."""
+    torch.manual_seed(0)
+    E, H1, W1, L, r = 20, 48, 64, 4, 3
+    vols = [torch.randn(E, H1, W1, H1 >> l, W1 >> l, device="cuda") for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H1, device="cuda").float(), torch.arange(W1, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys])[None] + 3 * torch.randn(E, 2, H1, W1, device="cuda")).contiguous()
+    o0 = 4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda"))
+    o1 = (4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda")) + o0) / 2
+    offs = [o0, o1, None, None]
+    out = lgu.ops.defcorr_pyramid_forward(vols, coords, offs, r)
+    assert out.shape == (E, 196, H1, W1) and torch.isfinite(out).all()
+    again = lgu.ops.defcorr_pyramid_forward(vols, coords, offs, r)
+    assert torch.equal(out, again)  # deterministic + centre zeroing idempotent
+    assert (o0[:, :, :, 3, 3] == 0).all() and (o1[:, :, :, 3, 3] == 0).all()
+    # per-level launches through the reference-shaped op agree bit-for-bit with the fused launch
+    for l in range(L):
+        off_l = offs[l] if offs[l] is not None else torch.zeros_like(o0)
+        c, = lgu.ops.defCorr_index_forward(vols[l], (coords / 2 ** l).contiguous(), off_l, r)
+        assert torch.equal(c.view(E, 49, H1, W1), out[:, 49 * l:49 * (l + 1)])
+    # linearity in the volume: f(2v + w) == 2 f(v) + f(w) to rounding
+    w = [torch.randn_like(v) for v in vols]
+    lhs = lgu.ops.defcorr_pyramid_forward([2 * v + x for v, x in zip(vols, w)], coords, offs, r)
+    rhs = 2 * out + lgu.ops.defcorr_pyramid_forward(w, coords, offs, r)
+    assert (lhs - rhs).abs().max() <= 1e-4
+    # variants agree exactly
+    os.environ["LGU_DEFCORR_VARIANT"] = "2"
+    gen = lgu.ops.defcorr_pyramid_forward(vols, coords, offs, r)
+    assert torch.equal(gen, out)
+
+
+def test_corrblock_matches_reference_shaped_composition(lgu, oracle):
+    """Host glue: CorrBlock.__call__ (fused launch) == probe + mask + 4 per-level oracle
+    calls + cat, including the persistent offset[1] *= mask state across two calls."""
+    torch.manual_seed(3)
+    E, h, w = 2, 48, 64
+    dev_ = "cuda"
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    GA = lgu.GaussianMask(h, w).to(dev_)
+    torch.nn.init.normal_(GA.meanMap.weight, 0, 0.3)
+    f1 = torch.randn(1, E, 128, h, w, device=dev_) * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device=dev_) * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev_).float(), torch.arange(w, device=dev_).float(), indexing="ij")
+    with torch.no_grad():
+        blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        pyr = [host(v) for v in blk.corr_pyramid]
+        offs = [host(o.contiguous()).reshape(E, h, w, 7, 7, 2).copy() for o in blk.offset]
+        for it in range(2):
+            coords1 = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device=dev_))
+            got, mean_n, theta = blk(coords1)
+            assert got.shape == (1, E, 196, h, w) and mean_n.shape == (1, E, h, w, 2) and theta.shape == (1, E, h, w)
+            c = host(coords1.permute(0, 1, 4, 2, 3).contiguous().view(E, 2, h, w))
+            probe, = oracle.corr_index_forward(pyr[1], (c / 2).astype(np.float32), 1)
+            var = torch.var(torch.from_numpy(probe).permute(0, 3, 4, 1, 2), dim=[3, 4])
+            mask = torch.sigmoid(var).numpy().reshape(E, h, w, 1, 1, 1)
+            offs[1] = (offs[1] * mask).astype(np.float32)
+            want = oracle.defcorr_pyramid_forward(pyr, c, [offs[0], offs[1], None, None], 3)
+            assert np.abs(host(got)[0] - want).max() <= 2e-5, "call %d" % it
