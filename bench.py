@@ -108,7 +108,13 @@ def cpu_baseline(E, H1, W1, L, radius, budget_s=12.0):
     """torch-CPU F.grid_sample formulation (oracle/grid_sample_baseline.py) on all host
     cores, same input distribution, bounded sample."""
     from oracle import grid_sample_baseline as G
-    cores = os.cpu_count() or 1
+    # threads actually used: the cores this process may run on, capped at 32 (the torch-CPU
+    # gather stops scaling well before that and collapses when oversubscribed on big hosts)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
     Es = min(E, 4)
     vols, coords, offs = make_inputs(Es, H1, W1, L, radius, 999, torch.device("cpu"), from_fmaps=False)
