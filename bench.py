@@ -167,15 +167,12 @@ def main():
     E, H1, W1, L, R = args.edges, 48, 64, 4, 3
     vols, coords, offs = make_inputs(E, H1, W1, L, R, 1234 + rank, dev, from_fmaps=not args.randn_volumes)
     out = torch.empty(E, L * 49, H1, W1, device=dev)
-    coords_half = (coords / 2).contiguous()
     units = E * H1 * W1
 
     def step():
-        if args.probe:  # corr.py:94-99 — probe, variance, sigmoid, stateful offset[1] *= mask
-            probe, = ops.corr_index_forward(vols[1], coords_half, 1)
-            mask = torch.sigmoid(torch.var(probe.permute(0, 3, 4, 1, 2), dim=[3, 4])).view(E, H1, W1, 1, 1, 1)
-            offs[1].mul_(mask)
-        ops.defcorr_pyramid_forward(vols, coords, offs, R, out=out)
+        # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful
+        # offset[1] *= mask of corr.py:94-99 run inside the same launch
+        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=args.probe, out=out)
 
     def barrier():
         if world > 1:
@@ -238,7 +235,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_unit": A, "unique_volume_elements_per_unit": U,
-                         "kernel": "defcorr_pyr_kernel<3,1,1>", "device_ms_per_step": dev_ms / args.steps},
+                         "kernel": "defcorr_pyr_kernel<3,%s,12>" % ("true" if args.probe else "false"), "device_ms_per_step": dev_ms / args.steps},
             "cpu_baseline": None if args.no_cpu else cpu_baseline(E, H1, W1, L, R),
         }
         if exchange:

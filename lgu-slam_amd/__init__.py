@@ -9,7 +9,7 @@ module `lgu_slam_amd.py` at the repository root.
 import os
 import sys
 
-from . import _build, _lib, ops  # noqa: F401
+from . import _build, _lib, ops, sharded  # noqa: F401
 from .corr import AltCorrBlock, CorrBlock, CorrSampler, DefCorrSampler, per_Corr_Normalization  # noqa: F401
 from .gaussian_mask import GaussianMask, GaussianMaskCuda  # noqa: F401
 

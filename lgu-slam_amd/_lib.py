@@ -35,6 +35,13 @@ class LguLibraryError(RuntimeError):
     pass
 
 
+class UnsupportedShape(RuntimeError):
+    """The kernels do not serve this shape / argument pattern (LGU_E_UNSUPPORTED)."""
+
+
+LGU_E_UNSUPPORTED = 100002
+
+
 def so_path():
     return _build.SO_PATH
 
@@ -67,7 +74,7 @@ def load():
 def check(code, what):
     if code != 0:
         msg = load().lgu_error_string(code).decode()
-        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
+        raise (UnsupportedShape if code == LGU_E_UNSUPPORTED else RuntimeError)("%s failed: %s (code %d)" % (what, msg, code))
 
 
 def version():

@@ -13,7 +13,7 @@ construction.
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 
 class CorrSampler(torch.autograd.Function):
@@ -124,14 +124,14 @@ class CorrBlock:
         rd = 2 * self.radius + 1
         coords = coords.permute(0, 1, 4, 2, 3).contiguous().view(E, 2, ht, wd)
 
-        # uncertainty probe on level 1; the mask is folded into offset[1] and PERSISTS across
-        # calls, exactly like the reference (corr.py:94-99)
-        probe = CorrSampler.apply(self.corr_pyramid[1], coords / 2, 1)
-        self.offset[1] = self.offset[1] * _uncertainty_mask(probe)
-
         needs_grad = torch.is_grad_enabled() and (
             any(v.requires_grad for v in self.corr_pyramid) or any(o.requires_grad for o in self.offset))
         if needs_grad:
+            # training: reference-shaped composition through the autograd Functions.
+            # Uncertainty probe on level 1; the mask is folded into offset[1] and PERSISTS
+            # across calls, exactly like the reference (corr.py:94-99)
+            probe = CorrSampler.apply(self.corr_pyramid[1], coords / 2, 1)
+            self.offset[1] = self.offset[1] * _uncertainty_mask(probe)
             out = [DefCorrSampler.apply(self.corr_pyramid[i], coords / 2 ** i,
                                         self.offset[i].contiguous().view(E, ht, wd, rd, rd, 2), self.radius)
                    .view(batch, num, -1, ht, wd) for i in range(self.num_levels)]
@@ -148,7 +148,16 @@ class CorrBlock:
                 self.offset[i] = o  # keep the buffer the kernel zeroes the centre of
             offs.append(o.view(E, ht, wd, rd, rd, 2))
         pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
-        out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius)
+        # inference: probe + mask + all levels + concatenation in ONE launch; offset[1] is
+        # scaled in place by the kernel (the same persistent state as above)
+        try:
+            out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius, probe=True)
+        except _lib.UnsupportedShape:
+            # shapes the fused probe does not serve (e.g. W2 % 4 != 0): separate probe ops
+            probe, = ops.corr_index_forward(pyr[1], (coords / 2).contiguous(), 1)
+            self.offset[1] = (self.offset[1] * _uncertainty_mask(probe)).contiguous()
+            offs[1] = self.offset[1].view(E, ht, wd, rd, rd, 2)
+            out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius)
         return out.view(batch, num, -1, ht, wd), self.mean_n, self.theta
 
     def cat(self, other):

@@ -31,9 +31,9 @@ constexpr int TP = 16;               // pixels (along x) per workgroup
 constexpr int NWAVE = 4;             // waves per workgroup
 constexpr int PPW = TP / NWAVE;      // pixels per wave
 constexpr int FASTL = 4;             // levels served by one launch of the fast kernel
-constexpr int POOL_FLOATS = 4096;    // 16 KiB of staging pool per wave
+constexpr int POOL_FLOATS = 2560;    // 10 KiB of staging pool per wave: 8 worst-case boxes of 16 rows x 5 granules
 constexpr int OUT_PITCH = TP + 1;    // transpose tile pitch (conflict-free column writes)
-constexpr int REG_GRAN = 2;          // register-staged variant: granules held per lane per job
+constexpr int MAX_GRAN = 2 * kWave;  // granules per staged job (two DMA instructions per lane)
 
 struct PyrParams {
   const float* vol[FASTL];
@@ -50,35 +50,10 @@ struct PyrParams {
   int flags;
 };
 
-enum JobMode : int { JOB_EMPTY = 0, JOB_STAGED = 1, JOB_DIRECT = 2 };
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int R>
-struct TapGeom {
-  int x1, y1;
-  float dx, dy;
-  bool valid;
-};
-
-template <int R>
-__device__ __forceinline__ TapGeom<R> tap_geom(float ofsX, float ofsY, int ti, int tj, int H2, int W2,
-                                               bool active) {
-  TapGeom<R> g;
-  const int fx = (int)floorf(ofsX);
-  const int fy = (int)floorf(ofsY);
-  g.dx = ofsX - (float)fx;  // :60-61
-  g.dy = ofsY - (float)fy;
-  g.x1 = fx - R + ti;  // :63-66
-  g.y1 = fy - R + tj;
-  g.valid = active && in_bounds(g.y1, g.x1, H2, W2);  // :67 whole-tap rule
-  return g;
-}
-
-// ---- tap-box reduction ---------------------------------------------------------------
-// Box corners packed as two int16 (x in the low half, y in the high half) so that ONE
-// component-wise packed min (v_pk_min_i16) and ONE packed max serve both axes.
+// ---- packed int16 pairs (x low, y high): one v_pk_min_i16 / v_pk_max_i16 serves both axes
 typedef short __attribute__((ext_vector_type(2))) short2v;
 
 __device__ __forceinline__ int pk16(int x, int y) { return (x & 0xffff) | (y << 16); }
@@ -90,69 +65,87 @@ __device__ __forceinline__ int pk_min(int a, int b) {
 __device__ __forceinline__ int pk_max(int a, int b) {
   return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
 }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// RED = 1: DPP within each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), then the
-// four row results are read with v_readlane and combined.  RED = 0: ds_bpermute butterfly.
-template <int RED, bool IS_MIN>
+// Wave-wide packed min/max: DPP inside each row of 16 lanes (xor 1, xor 2, half-mirror,
+// mirror), then the four row results are read with v_readlane and combined (wave-uniform).
+template <bool IS_MIN>
 __device__ __forceinline__ int wave_pk_reduce(int v) {
-  if (RED == 1) {
-#define LGU_DPP_STEP(ctrl)                                                       \
-  {                                                                              \
-    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);      \
-    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                                    \
+#define LGU_DPP_STEP(ctrl)                                                  \
+  {                                                                         \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false); \
+    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                               \
   }
-    LGU_DPP_STEP(0xB1)   // quad_perm:[1,0,3,2]
-    LGU_DPP_STEP(0x4E)   // quad_perm:[2,3,0,1]
-    LGU_DPP_STEP(0x141)  // row_half_mirror
-    LGU_DPP_STEP(0x140)  // row_mirror
+  LGU_DPP_STEP(0xB1)   // quad_perm:[1,0,3,2]
+  LGU_DPP_STEP(0x4E)   // quad_perm:[2,3,0,1]
+  LGU_DPP_STEP(0x141)  // row_half_mirror
+  LGU_DPP_STEP(0x140)  // row_mirror
 #undef LGU_DPP_STEP
-    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-    return IS_MIN ? pk_min(pk_min(r0, r1), pk_min(r2, r3)) : pk_max(pk_max(r0, r1), pk_max(r2, r3));
-  } else {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const int o = __shfl_xor(v, m, kWave);
-      v = IS_MIN ? pk_min(v, o) : pk_max(v, o);
-    }
-    return __builtin_amdgcn_readfirstlane(v);
-  }
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return IS_MIN ? pk_min(pk_min(r0, r1), pk_min(r2, r3)) : pk_max(pk_max(r0, r1), pk_max(r2, r3));
+}
+
+// Sum over each row of 16 lanes (every lane of the row gets the row total).
+__device__ __forceinline__ float row16_sum(float v) {
+#define LGU_SUM_STEP(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+  LGU_SUM_STEP(0xB1)
+  LGU_SUM_STEP(0x4E)
+  LGU_SUM_STEP(0x141)
+  LGU_SUM_STEP(0x140)
+#undef LGU_SUM_STEP
+  return v;
 }
 
 // One (pixel, level) job served with direct global gathers: the rare case of a tap box
 // that does not fit the wave's LDS pool (offsets far outside the +-4 the network emits).
-// Kept out of line so that the 16 unrolled fast-path bodies stay small.
+// Kept out of line so that the unrolled fast-path bodies stay small.  (ox, oy) is this
+// lane's offset pair, centre already 0 and probe mask already applied.
 template <int R>
-__device__ __noinline__ void direct_job(const float* __restrict__ slice, const float* __restrict__ offp, float cx,
-                                         float cy, int H2, int W2, float* outcol, int lane) {
+__device__ __noinline__ void direct_job(const float* __restrict__ slice, float ox, float oy, float cx, float cy,
+                                         int H2, int W2, float* outcol, int lane) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   if (lane >= NT) return;
   const int ti = lane / RD, tj = lane - ti * RD;
-  float ox = 0.0f, oy = 0.0f;
-  if (offp != nullptr && !(ti == R && tj == R)) {
-    const float2 o = reinterpret_cast<const float2*>(offp)[lane];
-    ox = o.x; oy = o.y;
-  }
-  const TapGeom<R> g = tap_geom<R>(ox + cx, oy + cy, ti, tj, H2, W2, true);
+  const float ofsX = ox + cx, ofsY = oy + cy;
+  const int fx = (int)floorf(ofsX), fy = (int)floorf(ofsY);
+  const float dx = ofsX - (float)fx, dy = ofsY - (float)fy;
+  const int x1 = fx - R + ti, y1 = fy - R + tj;
   float val = 0.0f;
-  if (g.valid) {
-    const float* s = slice + (size_t)g.y1 * W2 + g.x1;
-    const bool xin = g.x1 + 1 < W2, yin = g.y1 + 1 < H2;
+  if (in_bounds(y1, x1, H2, W2)) {
+    const float* s = slice + (size_t)y1 * W2 + x1;
+    const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;
     const float q11 = s[0];
     const float q21 = xin ? s[1] : 0.0f;
     const float q12 = yin ? s[W2] : 0.0f;
     const float q22 = (xin && yin) ? s[W2 + 1] : 0.0f;
-    val = bilerp(q11, q21, q12, q22, g.dx, g.dy);
+    val = bilerp(q11, q21, q12, q22, dx, dy);
   }
   outcol[lane * OUT_PITCH] = val;
 }
 
-// STAGE = 0: register staging (global_load_dwordx4 -> ds_write_b128)
-// STAGE = 1: LDS-DMA (global_load_lds_dwordx4)
-template <int R, int STAGE, int RED>
+// The fused sampler.  Per (pixel, level) job one of two modes:
+//  * STAGED  (level has an offset tensor): lanes = taps; tap box by a packed DPP reduction;
+//    the box's 16-byte granules go to LDS by LDS-DMA; taps blend from LDS.
+//  * LATTICE (offsets structurally zero: all taps share one fractional part and sit on a
+//    (2R+2)^2 integer lattice): lanes = lattice points, ONE 4-byte load per lane, taps
+//    gather their four corners from the lattice with ds_bpermute.  No LDS, no reduction.
+//    For R = 1 the 4x4 lattices of the wave's four pixels share one wave instruction.
+// PROBE additionally evaluates the 3x3 plain sample of level 1 (lattice mode, lanes 0..15),
+// its unbiased variance, mask = sigmoid(var), scales this pixel's level-1 offsets by it
+// (written back: the reference's persistent offset[1] *= mask, corr.py:94-99) before level
+// 1 is sampled.  The level-1 box is made conservative (covers mask = 0..1) so staging never
+// waits for the probe.
+// ZMASK: bit l set = level l of this launch has structurally zero offsets (LATTICE mode),
+// fixed at compile time so that each job carries the code of one mode only.
+template <int R, bool PROBE, int ZMASK>
 __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
-  static_assert(NT <= kWave, "lanes = taps needs rd*rd <= 64");
+  constexpr int LAT = 2 * R + 2;                 // lattice side
+  constexpr int LATP = LAT <= 4 ? 4 : 8;         // lattice pitch in lanes
+  constexpr int PIXOP = kWave / (LATP * LATP);   // pixels per lattice instruction: 4 (R=1) or 1
+  static_assert(NT <= kWave && LAT <= LATP, "lanes = taps / lattice points must fit one wave");
   extern __shared__ float4 lds4[];
   float* const lds = reinterpret_cast<float*>(lds4);
   // layout: [NWAVE][POOL_FLOATS] staging pools, then the [L*NT][OUT_PITCH] transpose tile
@@ -169,10 +162,19 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
   const int e = bid / p.H1;
   const int xbase = tile * TP;
 
+  // staged-mode lane roles: lane t = tap (i = t / RD moves in x, j = t % RD in y)
   const bool tap = lane < NT;
-  const int ti = lane / RD;       // tap index i moves in x
-  const int tj = lane - ti * RD;  // j moves in y
+  const int ti = lane / RD, tj = lane - ti * RD;
   const bool centre = (ti == R) && (tj == R);
+  // lattice-mode lane roles
+  const int lpix = PIXOP == 1 ? 0 : lane / (LATP * LATP);   // pixel slot of this lane (R = 1 only)
+  const int lq = lane & (LATP * LATP - 1);
+  const int ly = lq / LATP, lx = lq & (LATP - 1);
+  const bool lat_on = ly < LAT && lx < LAT;
+  const bool ltap = lq < NT;                                 // lattice-mode tap lanes (per pixel slot)
+  const int lti = PIXOP == 1 ? ti : lq / RD, ltj = PIXOP == 1 ? tj : lq - (lq / RD) * RD;
+  const int lsrc = (lane - lq) + ltj * LATP + lti;           // lattice lane holding this tap's top-left
+
   const size_t HW1 = (size_t)p.H1 * p.W1;
   const size_t row_pix = ((size_t)e * p.H1 + y) * p.W1;  // pixel index of (e, y, 0)
 
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
     for (int l = 0; l < FASTL; l++) {
       off[k][l] = make_float2(0.0f, 0.0f);
       // the centre tap's offset is forced to 0 (defCorrSample_kernel.cu:51-52): never read it
-      if (l < p.L && p.off[l] != nullptr && pv && tap && !centre)
+      if (!((ZMASK >> l) & 1) && l < p.L && pv && tap && !centre)
         off[k][l] = reinterpret_cast<const float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane];
     }
   }
@@ -202,56 +204,100 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
       if (px >= p.W1) continue;
 #pragma unroll
       for (int l = 0; l < FASTL; l++)
-        if (l < p.L && p.off[l] != nullptr)
+        if (!((ZMASK >> l) & 1) && l < p.L)
           reinterpret_cast<float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane] = make_float2(0.0f, 0.0f);
     }
   }
 
-  // ---- phase 0.5 (unconditional, top level): sample position of every job's tap.
-  // ofs = offset + coords / 2^l (defCorrSample_kernel.cu:56-57; corr.py:102, the power-of-two
-  // scale is exact).  Consuming every offset register here, outside any branch, makes the
-  // compiler retire the phase-0 loads once instead of draining the LDS-DMA queue per job.
-  float2 ofs[PPW][FASTL];
+  // ---- phase 0.5 (unconditional, top level): consume every phase-0 register once, outside
+  // any branch, so the compiler retires those loads here instead of draining the LDS-DMA
+  // queue in front of each job.  cs = coords / 2^l (corr.py:102; the scale is exact).
+  float2 cs[PPW][FASTL], ofs[PPW][FASTL];
 #pragma unroll
   for (int l = 0; l < FASTL; l++) {
     const float sc = __builtin_ldexpf(1.0f, -(p.lbase + l));
 #pragma unroll
-    for (int k = 0; k < PPW; k++) ofs[k][l] = make_float2(off[k][l].x + x0[k] * sc, off[k][l].y + y0[k] * sc);
+    for (int k = 0; k < PPW; k++) {
+      cs[k][l] = make_float2(x0[k] * sc, y0[k] * sc);
+      ofs[k][l] = make_float2(off[k][l].x + cs[k][l].x, off[k][l].y + cs[k][l].y);  // defCorrSample_kernel.cu:56-57
+    }
   }
 
-  // ---- phase A: per job, tap box -> LDS staging (issue everything) ----
-  // job record (wave-uniform): base = pool offset in floats, org = ylo*rowp + x4lo folded
-  // into one subtrahend, rowp = LDS row pitch in floats
-  int jbase[PPW][FASTL], jorg[PPW][FASTL], jrowp[PPW][FASTL], jn[PPW][FASTL];
-  float4 streg[STAGE == 0 ? PPW : 1][STAGE == 0 ? FASTL : 1][REG_GRAN];
-  unsigned staged_mask = 0, direct_mask = 0;
+  // ---- phase A: issue every job's loads ----
+  int jbase[PPW][FASTL], jorg[PPW][FASTL], jrowp[PPW][FASTL];   // staged-job records (wave-uniform)
+  float latv[PPW][FASTL];                                       // lattice-job values (one per lane)
+  float platv[PPW];                                             // probe lattice values
+  unsigned staged_mask = 0, direct_mask = 0, lattice_mask = 0;
   int pool_used = 0;
 #pragma unroll
   for (int k = 0; k < PPW; k++) {
     const int px = xbase + w * PPW + k;
     const bool pv = px < p.W1;
+    platv[k] = 0.0f;
+    if (PROBE && pv) {  // 4x4 lattice of level 1 around coords/2 on lanes 0..15
+      const int H2 = p.H2[1], W2 = p.W2[1];
+      const int X = (int)floorf(cs[k][1].x) - 1 + (lane & 3), Y = (int)floorf(cs[k][1].y) - 1 + ((lane >> 2) & 3);
+      if (lane < 16 && in_bounds(Y, X, H2, W2))
+        platv[k] = p.vol[1][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+    }
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
-      jbase[k][l] = 0; jorg[k][l] = 0; jrowp[k][l] = 4; jn[k][l] = 0;
-      if (l >= p.L || !pv) continue;
+      jbase[k][l] = 0; jorg[k][l] = 0; jrowp[k][l] = 4; latv[k][l] = 0.0f;
+      if (l >= p.L) continue;
       const int H2 = p.H2[l], W2 = p.W2[l];
+      if ((ZMASK >> l) & 1) {
+        // ---- LATTICE job ----
+        if (PIXOP == 1) {
+          if (!pv) continue;
+          lattice_mask |= 1u << (k * FASTL + l);
+          const int X = (int)floorf(cs[k][l].x) - R + lx, Y = (int)floorf(cs[k][l].y) - R + ly;
+          if (lat_on && in_bounds(Y, X, H2, W2))
+            latv[k][l] = p.vol[l][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+        } else if (k == 0) {  // one instruction covers the wave's PIXOP pixels
+          lattice_mask |= 1u << (k * FASTL + l);
+          const int pxl = xbase + w * PPW + lpix;
+          float cxl = cs[0][l].x, cyl = cs[0][l].y;
+#pragma unroll
+          for (int kk = 1; kk < PPW; kk++)
+            if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
+          const int X = (int)floorf(cxl) - R + lx, Y = (int)floorf(cyl) - R + ly;
+          if (pxl < p.W1 && lpix < PPW && lat_on && in_bounds(Y, X, H2, W2))
+            latv[k][l] = p.vol[l][(row_pix + pxl) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+        }
+        continue;
+      }
+      // ---- STAGED job ----
+      if (!pv) continue;
       int ylo, yhi, ga, gb;
       if (H2 * W2 <= 4 * kWave) {
         // small slice (<= 1 KiB): stage all of it with one wave instruction, no reduction
         ylo = 0; yhi = H2 - 1; ga = 0; gb = (W2 >> 2) - 1;
       } else {
-        const TapGeom<R> g = tap_geom<R>(ofs[k][l].x, ofs[k][l].y, ti, tj, H2, W2, tap);
-        const int xh = g.x1 + 1 < W2 ? g.x1 + 1 : W2 - 1;
-        const int yh = g.y1 + 1 < H2 ? g.y1 + 1 : H2 - 1;
-        const int lo = wave_pk_reduce<RED, true>(g.valid ? pk16(g.x1, g.y1) : 0x7fff7fff);
-        const int hi = wave_pk_reduce<RED, false>(g.valid ? pk16(xh, yh) : (int)0x80008000);
+        const int fx = (int)floorf(ofs[k][l].x), fy = (int)floorf(ofs[k][l].y);
+        int xa = fx - R + ti, ya = fy - R + tj;   // top-left of this tap
+        int xb = xa, yb = ya;
+        bool part = tap && in_bounds(ya, xa, H2, W2);
+        if (PROBE && l == 1) {
+          // the mask in (0.5, 1] moves the tap between its zero-offset and full-offset
+          // positions: cover both, clamped, unless the whole span is out of bounds
+          const int xz = (int)floorf(cs[k][l].x) - R + ti, yz = (int)floorf(cs[k][l].y) - R + tj;
+          const int xmn = xa < xz ? xa : xz, xmx = xa < xz ? xz : xa;
+          const int ymn = ya < yz ? ya : yz, ymx = ya < yz ? yz : ya;
+          part = tap && !(xmx < 0 || xmn >= W2 || ymx < 0 || ymn >= H2);
+          xa = clampi(xmn, 0, W2 - 1); xb = clampi(xmx, 0, W2 - 1);
+          ya = clampi(ymn, 0, H2 - 1); yb = clampi(ymx, 0, H2 - 1);
+        }
+        const int xh = xb + 1 < W2 ? xb + 1 : W2 - 1;
+        const int yh = yb + 1 < H2 ? yb + 1 : H2 - 1;
+        const int lo = wave_pk_reduce<true>(part ? pk16(xa, ya) : 0x7fff7fff);
+        const int hi = wave_pk_reduce<false>(part ? pk16(xh, yh) : (int)0x80008000);
         ylo = pk_hi(lo); yhi = pk_hi(hi);
         ga = pk_lo(lo) >> 2; gb = pk_lo(hi) >> 2;
       }
       if (yhi < ylo) continue;  // no tap of this pixel touches the slice: outputs are all 0
       const int pitch = gb - ga + 1;
       const int n = (yhi - ylo + 1) * pitch;  // 16-byte granules in the box
-      if (n > REG_GRAN * kWave || pool_used + n * 4 > POOL_FLOATS) {
+      if (n > MAX_GRAN || pool_used + n * 4 > POOL_FLOATS) {
         direct_mask |= 1u << (k * FASTL + l);
         continue;
       }
@@ -259,67 +305,98 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
       jbase[k][l] = pool_used;
       jrowp[k][l] = pitch * 4;
       jorg[k][l] = ylo * pitch * 4 + ga * 4;
-      jn[k][l] = n;
       const float* slice = p.vol[l] + (row_pix + px) * ((size_t)H2 * W2);  // wave-uniform
       const float rp = 1.0f / (float)pitch;
 #pragma unroll
-      for (int q = 0; q < REG_GRAN; q++) {
+      for (int q = 0; q < MAX_GRAN / kWave; q++) {
         const int kk = q * kWave + lane;
         const int row = (int)(((float)kk + 0.5f) * rp);
         const int gq = kk - row * pitch;
         const unsigned voff = (unsigned)((ylo + row) * W2 + (ga + gq) * 4);
-        if (STAGE == 1) {
-          // LDS destination = wave-uniform base + lane*16 (the DMA's own addressing)
-          if (kk < n)
-            __builtin_amdgcn_global_load_lds((glb_void*)(slice + voff), (lds_void*)(pool + pool_used + q * kWave * 4),
-                                             16, 0, 0);
-        } else {
-          streg[k][l][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kk < n) streg[k][l][q] = *reinterpret_cast<const float4*>(slice + voff);
-        }
+        // LDS destination = wave-uniform base + lane*16 (the DMA's own addressing)
+        if (kk < n)
+          __builtin_amdgcn_global_load_lds((glb_void*)(slice + voff), (lds_void*)(pool + pool_used + q * kWave * 4), 16,
+                                           0, 0);
       }
       pool_used += n * 4;
     }
   }
 
-  if (STAGE == 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-#pragma unroll
-    for (int k = 0; k < PPW; k++)
-#pragma unroll
-      for (int l = 0; l < FASTL; l++) {
-        if (!(staged_mask & (1u << (k * FASTL + l)))) continue;
-#pragma unroll
-        for (int q = 0; q < REG_GRAN; q++) {
-          const int kk = q * kWave + lane;
-          if (kk < jn[k][l]) reinterpret_cast<float4*>(pool + jbase[k][l])[kk] = streg[k][l][q];
-        }
-      }
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase B: blend from LDS, park in the transpose tile ----
+  // ---- phase B: blend, park in the transpose tile ----
+  float pmask[PPW];
 #pragma unroll
   for (int k = 0; k < PPW; k++) {
     const int px = xbase + w * PPW + k;
     const bool pv = px < p.W1;
+    pmask[k] = 1.0f;
+    if (PROBE && pv) {
+      // 3x3 plain sample of level 1 (corrSample_kernel.cu:52-77) on lanes 0..8 from the 4x4 lattice
+      const int H2 = p.H2[1], W2 = p.W2[1];
+      const int pi = lane / 3, pj = lane - pi * 3;
+      const int src = (pj * 4 + pi) & 15;
+      const float q11 = __shfl(platv[k], src, kWave), q21 = __shfl(platv[k], src + 1, kWave);
+      const float q12 = __shfl(platv[k], src + 4, kWave), q22 = __shfl(platv[k], (src + 5) & 15, kWave);
+      const float fxs = floorf(cs[k][1].x), fys = floorf(cs[k][1].y);
+      const float dx = cs[k][1].x - fxs, dy = cs[k][1].y - fys;
+      const int x1 = (int)fxs - 1 + pi, y1 = (int)fys - 1 + pj;
+      float v = 0.0f;
+      if (lane < 9 && in_bounds(y1, x1, H2, W2)) v = bilerp(q11, q21, q12, q22, dx, dy);
+      // unbiased variance over the nine taps (torch.var, corr.py:96), sigmoid (corr.py:97)
+      const float mean = row16_sum(lane < 9 ? v : 0.0f) / 9.0f;
+      const float d = lane < 9 ? v - mean : 0.0f;
+      const float var = row16_sum(d * d) / 8.0f;
+      const float m = 1.0f / (1.0f + expf(-var));
+      pmask[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+      // offset[1] *= mask, persistent (corr.py:99); the centre stays 0
+      off[k][1].x *= pmask[k];
+      off[k][1].y *= pmask[k];
+      ofs[k][1] = make_float2(off[k][1].x + cs[k][1].x, off[k][1].y + cs[k][1].y);
+      if (tap && !centre) reinterpret_cast<float2*>(p.off[1] + (row_pix + px) * (NT * 2))[lane] = off[k][1];
+    }
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
-      if (l >= p.L || !pv) continue;
+      if (l >= p.L) continue;
+      const int H2 = p.H2[l], W2 = p.W2[l];
+      if ((ZMASK >> l) & 1) {
+        if (!(lattice_mask & (1u << (k * FASTL + l)))) continue;
+        float cxl = cs[k][l].x, cyl = cs[k][l].y;
+        int pxl = px;
+        if (PIXOP > 1) {
+          pxl = xbase + w * PPW + lpix;
+#pragma unroll
+          for (int kk = 1; kk < PPW; kk++)
+            if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
+        }
+        const float q11 = __shfl(latv[k][l], lsrc, kWave), q21 = __shfl(latv[k][l], lsrc + 1, kWave);
+        const float q12 = __shfl(latv[k][l], lsrc + LATP, kWave), q22 = __shfl(latv[k][l], lsrc + LATP + 1, kWave);
+        const float fxs = floorf(cxl), fys = floorf(cyl);
+        const float dx = cxl - fxs, dy = cyl - fys;  // corrSample_kernel.cu:52-53
+        const int x1 = (int)fxs - R + lti, y1 = (int)fys - R + ltj;
+        float val = 0.0f;
+        // out-of-bounds corners arrive as 0 from the lattice; the whole-tap rule (:60) on top
+        if (in_bounds(y1, x1, H2, W2)) val = bilerp(q11, q21, q12, q22, dx, dy);
+        if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < PPW))
+          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * OUT_PITCH + (w * PPW + (PIXOP == 1 ? k : lpix))] = val;
+        continue;
+      }
+      if (!pv) continue;
       float val = 0.0f;  // masked taps stay 0 like torch::zeros in the reference (:181-183)
       if (staged_mask & (1u << (k * FASTL + l))) {
-        const int H2 = p.H2[l], W2 = p.W2[l];
-        const TapGeom<R> g = tap_geom<R>(ofs[k][l].x, ofs[k][l].y, ti, tj, H2, W2, tap);
-        if (g.valid) {
-          const bool xin = g.x1 + 1 < W2, yin = g.y1 + 1 < H2;  // x2,y2 >= 0 follow from x1,y1 >= 0
+        const int fx = (int)floorf(ofs[k][l].x), fy = (int)floorf(ofs[k][l].y);
+        const float dx = ofs[k][l].x - (float)fx, dy = ofs[k][l].y - (float)fy;  // :60-61
+        const int x1 = fx - R + ti, y1 = fy - R + tj;                             // :63-66
+        if (tap && in_bounds(y1, x1, H2, W2)) {                                   // :67 whole-tap rule
+          const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;  // x2,y2 >= 0 follow from x1,y1 >= 0
           const int rowp = jrowp[k][l];
-          const float* s = pool + jbase[k][l] + (g.y1 * rowp + g.x1 - jorg[k][l]);
+          const float* s = pool + jbase[k][l] + (y1 * rowp + x1 - jorg[k][l]);
           const float q11 = s[0];
           const float q21 = xin ? s[1] : 0.0f;
           const float q12 = yin ? s[rowp] : 0.0f;
           const float q22 = (xin && yin) ? s[rowp + 1] : 0.0f;
-          val = bilerp(q11, q21, q12, q22, g.dx, g.dy);
+          val = bilerp(q11, q21, q12, q22, dx, dy);
         }
       }
       if (tap) outst[(l * NT + lane) * OUT_PITCH + (w * PPW + k)] = val;
@@ -329,12 +406,14 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
     const int j = __builtin_ctz(direct_mask);
     direct_mask &= direct_mask - 1;
     const int k = j / FASTL, l = j % FASTL;
+    float2 o = make_float2(0.f, 0.f), c = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int kk = 0; kk < PPW; kk++)
+#pragma unroll
+      for (int ll = 0; ll < FASTL; ll++)
+        if (j == kk * FASTL + ll) { o = off[kk][ll]; c = cs[kk][ll]; }
     const int px = xbase + w * PPW + k;
-    const float sc = __builtin_ldexpf(1.0f, -(p.lbase + l));
-    const float* offp = p.off[l] ? p.off[l] + (row_pix + px) * (NT * 2) : nullptr;
-    direct_job<R>(p.vol[l] + (row_pix + px) * ((size_t)p.H2[l] * p.W2[l]), offp,
-                  p.coords[((size_t)e * 2 + 0) * HW1 + (size_t)y * p.W1 + px] * sc,
-                  p.coords[((size_t)e * 2 + 1) * HW1 + (size_t)y * p.W1 + px] * sc, p.H2[l], p.W2[l],
+    direct_job<R>(p.vol[l] + (row_pix + px) * ((size_t)p.H2[l] * p.W2[l]), o.x, o.y, c.x, c.y, p.H2[l], p.W2[l],
                   outst + (l * NT) * OUT_PITCH + (w * PPW + k), lane);
   }
   __syncthreads();
@@ -404,10 +483,10 @@ static size_t pyr_lds_bytes(int L, int radius) {
   return sizeof(float) * ((size_t)NWAVE * POOL_FLOATS + (size_t)L * nt * OUT_PITCH);
 }
 
-template <int R, int STAGE, int RED>
+template <int R, bool PROBE, int ZMASK>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const size_t lds = pyr_lds_bytes(p.L, R);
-  auto kern = defcorr_pyr_kernel<R, STAGE, RED>;
+  auto kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -429,17 +508,39 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     return LGU_E_BADARG;
   for (int l = 0; l < L; l++)
     if (!volumes[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
-  if (flags & LGU_PYR_PROBE) return LGU_E_UNSUPPORTED;  // fused probe: see lgu_defcorr_pyramid_fwd_f32
+  const bool probe = (flags & LGU_PYR_PROBE) != 0;
+  if (probe && (L < 2 || offsets[1] == nullptr)) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production, 1/3/4 = see switch below,
-  // 2 = generic one-thread-per-output kernel
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production kernel, 2 = generic
+  // one-thread-per-output kernel (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
 
-  for (int l0 = 0; l0 < L; l0 += FASTL) {
-    const int nl = (L - l0) < FASTL ? (L - l0) : FASTL;
+  int l0 = 0;
+  while (l0 < L) {
+    // group up to FASTL consecutive levels into one launch; the kernel is specialised on which
+    // levels of the group have null (= zero) offsets: none, all, or "levels >= 2" (CorrBlock)
+    int nl = (L - l0) < FASTL ? (L - l0) : FASTL;
+    int zm = 0;
+    for (int l = 0; l < nl; l++)
+      if (offsets[l0 + l] == nullptr) zm |= 1 << l;
+    const int full = (1 << nl) - 1;
+    int tmpl;
+    if (zm == 0) tmpl = 0x0;
+    else if (zm == full) tmpl = 0xF;
+    else if (nl >= 3 && zm == (full & 0xC)) tmpl = 0xC;
+    else {  // mixed pattern: take the longest prefix of equal kind
+      const bool first = offsets[l0] == nullptr;
+      int m = 1;
+      while (m < nl && (offsets[l0 + m] == nullptr) == first) m++;
+      nl = m;
+      tmpl = first ? 0xF : 0x0;
+    }
+    const bool pr = probe && l0 == 0;
+    if (pr && (nl < 2 || tmpl == 0xF)) return LGU_E_UNSUPPORTED;  // host glue runs the probe as separate ops
+
     bool fast = (radius >= 1 && radius <= 3) && variant != 2 && aligned16(coords);
     for (int l = l0; l < l0 + nl; l++)
       fast = fast && (W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
@@ -457,18 +558,16 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       p.tiles_per_row = (W1 + TP - 1) / TP;
       p.Ctot = Ctot; p.cbase = l0 * nt; p.lbase = l0; p.flags = flags;
       int rc;
-#define LGU_LAUNCH_R(ST, RD_)                                                            \
-  (radius == 3 ? launch_fast<3, ST, RD_>(p, st)                                          \
-               : radius == 2 ? launch_fast<2, ST, RD_>(p, st) : launch_fast<1, ST, RD_>(p, st))
-      switch (variant) {
-        case 1: rc = LGU_LAUNCH_R(0, 1); break;   // register staging + DPP box reduction
-        case 3: rc = LGU_LAUNCH_R(1, 0); break;   // LDS-DMA + ds_bpermute box reduction
-        case 4: rc = LGU_LAUNCH_R(0, 0); break;   // register staging + ds_bpermute
-        default: rc = LGU_LAUNCH_R(1, 1); break;  // LDS-DMA + DPP (production)
-      }
-#undef LGU_LAUNCH_R
+#define LGU_LAUNCH(PR, ZM)                                                                  \
+  (radius == 3 ? launch_fast<3, PR, ZM>(p, st)                                              \
+               : radius == 2 ? launch_fast<2, PR, ZM>(p, st) : launch_fast<1, PR, ZM>(p, st))
+      if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
+      else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
+#undef LGU_LAUNCH
       if (rc != LGU_OK) return rc;
     } else {
+      // the generic kernel has no fused probe: the host glue then runs the probe as separate ops
+      if (pr) return LGU_E_UNSUPPORTED;
       for (int l = l0; l < l0 + nl; l++) {
         const size_t total = (size_t)E * nt * H1 * W1;
         const unsigned grid = (unsigned)((total + 255) / 256 < 65535u * 16 ? (total + 255) / 256 : 65535u * 16);
@@ -478,6 +577,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
         if (rc != LGU_OK) return rc;
       }
     }
+    l0 += nl;
   }
   return LGU_OK;
 }

@@ -49,9 +49,9 @@ def main(outdir):
 
     # --- defCorr_index forward/backward + corr_index forward/backward ---
     for tag, (E, H1, W1, H2, W2, r, sigma, cscale) in {
-        "defcorr_r3_interior": (2, 12, 16, 12, 16, 3, 2.0, 1.0),
-        "defcorr_r3_border": (2, 12, 16, 6, 8, 3, 6.0, 0.5),   # level-1-like: coords/2, many OOB taps
-        "defcorr_r1": (2, 8, 16, 8, 16, 1, 3.0, 1.0),
+        "defcorr_r3_interior": (1, 8, 16, 8, 16, 3, 1.5, 1.0),
+        "defcorr_r3_border": (2, 8, 16, 4, 8, 3, 5.0, 0.5),   # level-1-like: coords/2, many OOB taps
+        "defcorr_r1": (1, 8, 16, 8, 16, 1, 3.0, 1.0),
     }.items():
         rd = 2 * r + 1
         vol = rng.standard_normal((E, H1, W1, H2, W2)).astype(np.float32)
@@ -69,7 +69,7 @@ def main(outdir):
              volume_grad=host(vg), offset_grad=host(og), plain_corr=host(pc), plain_volume_grad=host(pvg))
 
     # --- gaussianMask forward/backward ---
-    E, H1, W1 = 2, 12, 16
+    E, H1, W1 = 1, 8, 16
     vol = rng.standard_normal((E, H1, W1, H1, W1)).astype(np.float32)
     ys, xs = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
     means = (np.stack([xs, ys], -1)[None].repeat(E, 0) + 2 * rng.standard_normal((E, H1, W1, 2))).astype(np.float32)
@@ -82,8 +82,8 @@ def main(outdir):
 
     # --- lowMem_defSample ---
     for tag, (B, S, H1, W1, H2, W2, C, r, sigma, cscale) in {
-        "lowmem_l0": (3, 1, 8, 16, 8, 16, 128, 3, 2.0, 1.0),
-        "lowmem_l1": (2, 1, 8, 16, 4, 8, 128, 3, 4.0, 0.5),
+        "lowmem_l0": (2, 1, 8, 16, 8, 16, 128, 3, 2.0, 1.0),
+        "lowmem_l1": (2, 1, 8, 16, 4, 8, 64, 3, 4.0, 0.5),
     }.items():
         case = inputs.fmap_case(int(rng.integers(1 << 30)), B, S, H1, W1, H2, W2, C, r, sigma, cscale)
         o = dev(case["offset"])
@@ -92,7 +92,7 @@ def main(outdir):
 
     # --- altcorr forward/backward ---
     for tag, (B, S, H1, W1, H2, W2, C, r, sigma, cscale) in {
-        "altcorr_r1": (2, 1, 8, 16, 4, 8, 128, 1, 4.0, 0.5),
+        "altcorr_r1": (2, 1, 8, 16, 4, 8, 64, 1, 4.0, 0.5),
         "altcorr_r3": (1, 2, 8, 16, 8, 16, 64, 3, 3.0, 1.0),
     }.items():
         case = inputs.fmap_case(int(rng.integers(1 << 30)), B, S, H1, W1, H2, W2, C, r, sigma, cscale)
@@ -104,8 +104,8 @@ def main(outdir):
 
     # --- pyramid composition exactly as CorrBlock.__call__ drives the reference ops
     # (corr.py:94-109): probe r=1 on level 1, var, sigmoid, offset[1] *= mask, 4 levels, cat
-    case = inputs.pyramid_case(77, 1, 24, 32, 3, 3, 3.0, 4.0, False)
-    E, H1, W1 = 1, 24, 32
+    case = inputs.pyramid_case(77, 1, 16, 16, 3, 3, 3.0, 4.0, False)
+    E, H1, W1 = 1, 16, 16
     vols = [dev(v) for v in case["volumes"]]
     coords = dev(case["coords"])
     offs = [dev(o) if o is not None else torch.zeros(E, H1, W1, 7, 7, 2, device="cuda") for o in case["offsets"]]
