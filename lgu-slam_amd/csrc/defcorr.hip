@@ -427,6 +427,234 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-gather variant of the fused sampler: same decomposition (workgroup = 16 pixels of
+// one row, wave = 4 pixels, lanes = taps / lattice points, LDS transpose tile for the
+// write-out) but offset levels fetch their four corners with plain per-lane global loads
+// instead of staging the tap box in LDS.  All taps of a pixel sit in one wave instruction,
+// so the ~20 lines a pixel touches are shared by the 49 lanes of each load and stay in the
+// CU's L1 for the other three corners.  Every load of the wave's 16 jobs is issued before
+// the first result is used.  Far fewer instructions per pixel than the LDS-DMA kernel; the
+// price is L1/TA work per corner instead of per line.
+template <int R, bool PROBE, int ZMASK>
+__global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const PyrParams p) {
+  constexpr int RD = 2 * R + 1, NT = RD * RD;
+  constexpr int LAT = 2 * R + 2;
+  constexpr int LATP = LAT <= 4 ? 4 : 8;
+  constexpr int PIXOP = kWave / (LATP * LATP);
+  extern __shared__ float4 lds4[];
+  float* const outst = reinterpret_cast<float*>(lds4);  // [L*NT][OUT_PITCH]
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bid = blockIdx.x;
+  const int tile = bid % p.tiles_per_row;
+  bid /= p.tiles_per_row;
+  const int y = bid % p.H1;
+  const int e = bid / p.H1;
+  const int xbase = tile * TP;
+
+  const bool tap = lane < NT;
+  const int ti = lane / RD, tj = lane - ti * RD;
+  const bool centre = (ti == R) && (tj == R);
+  const int lpix = PIXOP == 1 ? 0 : lane / (LATP * LATP);
+  const int lq = lane & (LATP * LATP - 1);
+  const int ly = lq / LATP, lx = lq & (LATP - 1);
+  const bool lat_on = ly < LAT && lx < LAT;
+  const bool ltap = lq < NT;
+  const int lti = PIXOP == 1 ? ti : lq / RD, ltj = PIXOP == 1 ? tj : lq - (lq / RD) * RD;
+  const int lsrc = (lane - lq) + ltj * LATP + lti;
+
+  const size_t HW1 = (size_t)p.H1 * p.W1;
+  const size_t row_pix = ((size_t)e * p.H1 + y) * p.W1;
+
+  // ---- phase 0: coords + offsets ----
+  float x0[PPW], y0[PPW];
+  float2 off[PPW][FASTL];
+#pragma unroll
+  for (int k = 0; k < PPW; k++) {
+    const int px = xbase + w * PPW + k;
+    const bool pv = px < p.W1;
+    x0[k] = pv ? p.coords[((size_t)e * 2 + 0) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
+    y0[k] = pv ? p.coords[((size_t)e * 2 + 1) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
+#pragma unroll
+    for (int l = 0; l < FASTL; l++) {
+      off[k][l] = make_float2(0.0f, 0.0f);
+      if (!((ZMASK >> l) & 1) && l < p.L && pv && tap && !centre)
+        off[k][l] = reinterpret_cast<const float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane];
+    }
+  }
+  if (centre) {  // reference side effect (defCorrSample_kernel.cu:51-52)
+#pragma unroll
+    for (int k = 0; k < PPW; k++) {
+      const int px = xbase + w * PPW + k;
+      if (px >= p.W1) continue;
+#pragma unroll
+      for (int l = 0; l < FASTL; l++)
+        if (!((ZMASK >> l) & 1) && l < p.L)
+          reinterpret_cast<float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane] = make_float2(0.0f, 0.0f);
+    }
+  }
+  float2 cs[PPW][FASTL];
+#pragma unroll
+  for (int l = 0; l < FASTL; l++) {
+    const float sc = __builtin_ldexpf(1.0f, -(p.lbase + l));
+#pragma unroll
+    for (int k = 0; k < PPW; k++) cs[k][l] = make_float2(x0[k] * sc, y0[k] * sc);
+  }
+
+  // ---- phase A: issue every load.  Order: probe lattices first (the level-1 gathers wait
+  // for them), then everything that does not depend on the probe, then level 1.
+  float platv[PPW];
+  float latv[PPW][FASTL];
+  float q[PPW][FASTL][4];
+  float gdx[PPW][FASTL], gdy[PPW][FASTL];
+  int gflag[PPW][FASTL];  // bit0 tap valid, bit1 x2 in bounds, bit2 y2 in bounds
+#pragma unroll
+  for (int k = 0; k < PPW; k++) {
+    platv[k] = 0.0f;
+    const int px = xbase + w * PPW + k;
+    if (PROBE && px < p.W1) {
+      const int H2 = p.H2[1], W2 = p.W2[1];
+      const int X = (int)floorf(cs[k][1].x) - 1 + (lane & 3), Y = (int)floorf(cs[k][1].y) - 1 + ((lane >> 2) & 3);
+      if (lane < 16 && in_bounds(Y, X, H2, W2))
+        platv[k] = p.vol[1][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+    }
+  }
+
+  auto issue_level = [&](int k, int l) __attribute__((always_inline)) {
+    const int px = xbase + w * PPW + k;
+    const bool pv = px < p.W1;
+    const int H2 = p.H2[l], W2 = p.W2[l];
+    const float ofsX = off[k][l].x + cs[k][l].x, ofsY = off[k][l].y + cs[k][l].y;  // :56-57
+    const int fx = (int)floorf(ofsX), fy = (int)floorf(ofsY);
+    gdx[k][l] = ofsX - (float)fx;
+    gdy[k][l] = ofsY - (float)fy;
+    const int x1 = fx - R + ti, y1 = fy - R + tj;
+    const bool valid = tap && pv && in_bounds(y1, x1, H2, W2);  // :67
+    // clamp so that every lane forms a legal address; results of clamped lanes are discarded
+    // in phase B (the loaded registers are NOT touched here, so nothing waits in phase A)
+    const int xc = clampi(x1, 0, W2 - 1), yc = clampi(y1, 0, H2 - 1);
+    const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;
+    gflag[k][l] = (valid ? 1 : 0) | (xin ? 2 : 0) | (yin ? 4 : 0);
+    const int dxo = xin ? 1 : 0, dyo = yin ? W2 : 0;
+    const float* s = p.vol[l] + (row_pix + (pv ? px : 0)) * ((size_t)H2 * W2) + (yc * W2 + xc);
+    q[k][l][0] = s[0];
+    q[k][l][1] = s[dxo];
+    q[k][l][2] = s[dyo];
+    q[k][l][3] = s[dyo + dxo];
+  };
+
+#pragma unroll
+  for (int k = 0; k < PPW; k++) {
+    const int px = xbase + w * PPW + k;
+    const bool pv = px < p.W1;
+#pragma unroll
+    for (int l = 0; l < FASTL; l++) {
+      latv[k][l] = 0.0f;
+      gdx[k][l] = gdy[k][l] = 0.0f;
+      gflag[k][l] = 0;
+      q[k][l][0] = q[k][l][1] = q[k][l][2] = q[k][l][3] = 0.0f;
+      if (l >= p.L) continue;
+      const int H2 = p.H2[l], W2 = p.W2[l];
+      if ((ZMASK >> l) & 1) {
+        if (PIXOP == 1) {
+          const int X = (int)floorf(cs[k][l].x) - R + lx, Y = (int)floorf(cs[k][l].y) - R + ly;
+          if (pv && lat_on && in_bounds(Y, X, H2, W2))
+            latv[k][l] = p.vol[l][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+        } else if (k == 0) {
+          const int pxl = xbase + w * PPW + lpix;
+          float cxl = cs[0][l].x, cyl = cs[0][l].y;
+#pragma unroll
+          for (int kk = 1; kk < PPW; kk++)
+            if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
+          const int X = (int)floorf(cxl) - R + lx, Y = (int)floorf(cyl) - R + ly;
+          if (pxl < p.W1 && lpix < PPW && lat_on && in_bounds(Y, X, H2, W2))
+            latv[k][l] = p.vol[l][(row_pix + pxl) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+        }
+      } else if (!(PROBE && l == 1)) {
+        issue_level(k, l);
+      }
+    }
+  }
+
+  // ---- probe -> mask -> level-1 offsets (corr.py:94-99), then the level-1 gathers ----
+  if (PROBE) {
+#pragma unroll
+    for (int k = 0; k < PPW; k++) {
+      const int px = xbase + w * PPW + k;
+      const bool pv = px < p.W1;
+      const int H2 = p.H2[1], W2 = p.W2[1];
+      const int pi = lane / 3, pj = lane - pi * 3;
+      const int src = (pj * 4 + pi) & 15;
+      const float q11 = __shfl(platv[k], src, kWave), q21 = __shfl(platv[k], src + 1, kWave);
+      const float q12 = __shfl(platv[k], src + 4, kWave), q22 = __shfl(platv[k], (src + 5) & 15, kWave);
+      const float fxs = floorf(cs[k][1].x), fys = floorf(cs[k][1].y);
+      const float dx = cs[k][1].x - fxs, dy = cs[k][1].y - fys;
+      const int x1 = (int)fxs - 1 + pi, y1 = (int)fys - 1 + pj;
+      float v = 0.0f;
+      if (lane < 9 && in_bounds(y1, x1, H2, W2)) v = bilerp(q11, q21, q12, q22, dx, dy);
+      const float mean = row16_sum(lane < 9 ? v : 0.0f) / 9.0f;
+      const float dd = lane < 9 ? v - mean : 0.0f;
+      const float var = row16_sum(dd * dd) / 8.0f;  // unbiased, torch.var default
+      const float m = 1.0f / (1.0f + expf(-var));
+      const float mk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+      off[k][1].x *= mk;
+      off[k][1].y *= mk;
+      if (pv && tap && !centre) reinterpret_cast<float2*>(p.off[1] + (row_pix + px) * (NT * 2))[lane] = off[k][1];
+      issue_level(k, 1);
+    }
+  }
+
+  // ---- phase B: blend, park in the transpose tile ----
+#pragma unroll
+  for (int k = 0; k < PPW; k++) {
+    const int px = xbase + w * PPW + k;
+    const bool pv = px < p.W1;
+#pragma unroll
+    for (int l = 0; l < FASTL; l++) {
+      if (l >= p.L) continue;
+      const int H2 = p.H2[l], W2 = p.W2[l];
+      if ((ZMASK >> l) & 1) {
+        if (PIXOP > 1 && k > 0) continue;
+        float cxl = cs[k][l].x, cyl = cs[k][l].y;
+        int pxl = px;
+        if (PIXOP > 1) {
+          pxl = xbase + w * PPW + lpix;
+#pragma unroll
+          for (int kk = 1; kk < PPW; kk++)
+            if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
+        }
+        const float q11 = __shfl(latv[k][l], lsrc, kWave), q21 = __shfl(latv[k][l], lsrc + 1, kWave);
+        const float q12 = __shfl(latv[k][l], lsrc + LATP, kWave), q22 = __shfl(latv[k][l], lsrc + LATP + 1, kWave);
+        const float fxs = floorf(cxl), fys = floorf(cyl);
+        const float dx = cxl - fxs, dy = cyl - fys;
+        const int x1 = (int)fxs - R + lti, y1 = (int)fys - R + ltj;
+        float val = 0.0f;
+        if (in_bounds(y1, x1, H2, W2)) val = bilerp(q11, q21, q12, q22, dx, dy);
+        if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < PPW))
+          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * OUT_PITCH + (w * PPW + (PIXOP == 1 ? k : lpix))] = val;
+        continue;
+      }
+      if (!pv) continue;
+      const int fl = gflag[k][l];
+      const float q21 = (fl & 2) ? q[k][l][1] : 0.0f;          // :76-80 out-of-range corners read as 0
+      const float q12 = (fl & 4) ? q[k][l][2] : 0.0f;
+      const float q22 = ((fl & 6) == 6) ? q[k][l][3] : 0.0f;
+      const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
+      if (tap) outst[(l * NT + lane) * OUT_PITCH + (w * PPW + k)] = val;
+    }
+  }
+  __syncthreads();
+
+  const int nout = p.L * NT * TP;
+  float* const orow = p.out + (((size_t)e * p.Ctot + p.cbase) * p.H1 + y) * p.W1 + xbase;
+  for (int idx = threadIdx.x; idx < nout; idx += NWAVE * kWave) {
+    const int c = idx >> 4, pc = idx & (TP - 1);
+    if (xbase + pc < p.W1) orow[(size_t)c * HW1 + pc] = outst[c * OUT_PITCH + pc];
+  }
+}
+
 // Generic fallback: one thread per output element (x fastest -> coalesced stores).
 // Serves any radius / any W2 / unaligned buffers; same arithmetic.
 __global__ __launch_bounds__(256) void defcorr_generic_kernel(const float* __restrict__ vol,
@@ -483,10 +711,12 @@ static size_t pyr_lds_bytes(int L, int radius) {
   return sizeof(float) * ((size_t)NWAVE * POOL_FLOATS + (size_t)L * nt * OUT_PITCH);
 }
 
-template <int R, bool PROBE, int ZMASK>
+// KIND 0: LDS-DMA staged kernel; KIND 1: register-gather kernel
+template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
-  const size_t lds = pyr_lds_bytes(p.L, R);
-  auto kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
+  const int nt_ = (2 * R + 1) * (2 * R + 1);
+  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * OUT_PITCH;
+  auto kern = KIND == 0 ? defcorr_pyr_kernel<R, PROBE, ZMASK> : defcorr_gather_kernel<R, PROBE, ZMASK>;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -514,7 +744,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production kernel, 2 = generic
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = register-gather kernel, 1 = LDS-DMA staged kernel, 2 = generic
   // one-thread-per-output kernel (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
 
@@ -558,12 +788,14 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       p.tiles_per_row = (W1 + TP - 1) / TP;
       p.Ctot = Ctot; p.cbase = l0 * nt; p.lbase = l0; p.flags = flags;
       int rc;
-#define LGU_LAUNCH(PR, ZM)                                                                  \
-  (radius == 3 ? launch_fast<3, PR, ZM>(p, st)                                              \
-               : radius == 2 ? launch_fast<2, PR, ZM>(p, st) : launch_fast<1, PR, ZM>(p, st))
+#define LGU_LAUNCH_K(PR, ZM, KD)                                                                   \
+  (radius == 3 ? launch_fast<3, PR, ZM, KD>(p, st)                                                 \
+               : radius == 2 ? launch_fast<2, PR, ZM, KD>(p, st) : launch_fast<1, PR, ZM, KD>(p, st))
+#define LGU_LAUNCH(PR, ZM) (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0) : LGU_LAUNCH_K(PR, ZM, 1))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
       else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
 #undef LGU_LAUNCH
+#undef LGU_LAUNCH_K
       if (rc != LGU_OK) return rc;
     } else {
       // the generic kernel has no fused probe: the host glue then runs the probe as separate ops

@@ -74,7 +74,7 @@ PYR_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", list(PYR_CASES))
 def test_defcorr_pyramid_matches_oracle(lgu, oracle, name, variant):
     seed, E, H1, W1, L, radius, sigma, osc, dense = PYR_CASES[name]
@@ -100,11 +100,13 @@ PROBE_CASES = {
 }
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", list(PROBE_CASES))
-def test_fused_probe_matches_oracle(lgu, oracle, name):
+def test_fused_probe_matches_oracle(lgu, oracle, name, variant):
     """LGU_PYR_PROBE: in-kernel 3x3 probe of level 1 -> var -> sigmoid -> offset[1] *= mask
     (written back) -> sample.  Two consecutive calls check the persistent compounding."""
     seed, E, H1, W1, L, radius, sigma, osc, dense = PROBE_CASES[name]
+    set_variant(variant)
     case = inputs.pyramid_case(seed, E, H1, W1, L, radius, sigma, osc, dense)
     ref_offs = [o.copy() if o is not None else None for o in case["offsets"]]
     vols = [dev(v) for v in case["volumes"]]
