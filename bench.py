@@ -221,6 +221,17 @@ def main():
 
     if rank == 0:
         A, U = algorithmic_bytes_per_unit(vols, coords, offs, R)
+        kname = {0: "defcorr_gather_kernel", 1: "defcorr_pyr_kernel", 2: "defcorr_generic_kernel"}.get(args.variant, "?")
+        kname = "lgu::%s<3,%s,12>" % (kname, "true" if args.probe else "false") if args.variant != 2 else "lgu::" + kname
+        # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
+        # because counters cannot be collected from inside the timed process; see profiles/.
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tfile) and E == 20 and not args.probe:
+            t = json.load(open(tfile))
+            if t.get("kernel") == kname:
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/traffic_r01.json"
         kern_s = dev_ms * 1e-3 / args.steps  # average launch-to-launch device time of the step
         achieved = A * units / kern_s / 1e9
         res = {
@@ -233,9 +244,10 @@ def main():
                        "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
                        "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": A * units,
                          "algorithmic_bytes_per_unit": A, "unique_volume_elements_per_unit": U,
-                         "kernel": "defcorr_pyr_kernel<3,%s,12>" % ("true" if args.probe else "false"), "device_ms_per_step": dev_ms / args.steps},
+                         "kernel": kname, "device_ms_per_step": dev_ms / args.steps},
             "cpu_baseline": None if args.no_cpu else cpu_baseline(E, H1, W1, L, R),
         }
         if exchange:
