@@ -17,14 +17,19 @@ from . import _lib
 _vp = ctypes.c_void_p
 
 
-def _check(t, name, dtype=torch.float32):
-    # reference: TORCH_CHECK(x.is_contiguous(), #x " must be contiguous")  (droid.cpp:48-49)
-    if not t.is_contiguous():
-        raise RuntimeError("%s must be contiguous" % name)
-    if not t.is_cuda:
-        raise RuntimeError("%s must be a HIP device tensor: lgu_slam_amd has no CPU fallback" % name)
-    if t.dtype != dtype:
-        raise RuntimeError("expected scalar type Float but found %s (%s)" % (str(t.dtype).replace("torch.", ""), name))
+def _check(*named):
+    """_check(volume, "volume", coords, "coords", ...): the reference's CHECK_INPUT on every
+    argument first (TORCH_CHECK(x.is_contiguous(), #x " must be contiguous"), droid.cpp:48-49),
+    then what this library additionally requires (HIP device, float32)."""
+    pairs = list(zip(named[0::2], named[1::2]))
+    for t, name in pairs:
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)
+    for t, name in pairs:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a HIP device tensor: lgu_slam_amd has no CPU fallback" % name)
+        if t.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float but found %s (%s)" % (str(t.dtype).replace("torch.", ""), name))
 
 
 def _stream(t):
@@ -36,7 +41,7 @@ def _ptr(t):
 
 
 def defCorr_index_forward(volume, coords, offset, radius):
-    _check(volume, "volume"); _check(coords, "coords"); _check(offset, "offset")
+    _check(volume, "volume", coords, "coords", offset, "offset")
     E, H1, W1, H2, W2 = volume.shape
     rd = 2 * radius + 1
     if tuple(coords.shape) != (E, 2, H1, W1) or offset.numel() != E * H1 * W1 * rd * rd * 2:
@@ -50,7 +55,7 @@ def defCorr_index_forward(volume, coords, offset, radius):
 
 
 def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
-    _check(volume, "volume"); _check(coords, "coords"); _check(offset, "offset"); _check(corr_grad, "corr_grad")
+    _check(volume, "volume", coords, "coords", offset, "offset", corr_grad, "corr_grad")
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
     offset_grad = torch.empty_like(offset)
@@ -63,7 +68,7 @@ def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
 
 
 def corr_index_forward(volume, coords, radius):
-    _check(volume, "volume"); _check(coords, "coords")
+    _check(volume, "volume", coords, "coords")
     E, H1, W1, H2, W2 = volume.shape
     rd = 2 * radius + 1
     if tuple(coords.shape) != (E, 2, H1, W1):
@@ -77,7 +82,7 @@ def corr_index_forward(volume, coords, radius):
 
 
 def corr_index_backward(volume, coords, corr_grad, radius):
-    _check(volume, "volume"); _check(coords, "coords"); _check(corr_grad, "corr_grad")
+    _check(volume, "volume", coords, "coords", corr_grad, "corr_grad")
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
     with torch.cuda.device(volume.device):
@@ -88,7 +93,7 @@ def corr_index_backward(volume, coords, corr_grad, radius):
 
 
 def gaussianMask(means, covs, volume, radius):
-    _check(volume, "volume"); _check(means, "means"); _check(covs, "covs")
+    _check(volume, "volume", means, "means", covs, "covs")
     E, H1, W1, H2, W2 = volume.shape
     volume1 = torch.empty_like(volume)
     with torch.cuda.device(volume.device):
@@ -99,7 +104,7 @@ def gaussianMask(means, covs, volume, radius):
 
 
 def gaussianMask_backward(means, covs, volume, volume_grad, radius):
-    _check(volume, "volume"); _check(means, "means"); _check(covs, "covs"); _check(volume_grad, "volume_grad")
+    _check(volume, "volume", means, "means", covs, "covs", volume_grad, "volume_grad")
     E, H1, W1, H2, W2 = volume.shape
     means_grad = torch.empty_like(means)
     covs_grad = torch.empty_like(covs)
@@ -112,7 +117,7 @@ def gaussianMask_backward(means, covs, volume, volume_grad, radius):
 
 
 def lowMem_defSample(fmap1, fmap2, coords, offset, radius):
-    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords"); _check(offset, "offset")
+    _check(fmap1, "fmap1", fmap2, "fmap2", coords, "coords", offset, "offset")
     B, S, H1, W1, _ = coords.shape
     _, H2, W2, C = fmap2.shape
     rd = 2 * radius + 1
@@ -126,7 +131,7 @@ def lowMem_defSample(fmap1, fmap2, coords, offset, radius):
 
 
 def altcorr_forward(fmap1, fmap2, coords, radius):
-    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords")
+    _check(fmap1, "fmap1", fmap2, "fmap2", coords, "coords")
     B, S, H1, W1, _ = coords.shape
     _, H2, W2, C = fmap2.shape
     rd = 2 * radius + 1
@@ -139,7 +144,7 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
 
 
 def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
-    _check(fmap1, "fmap1"); _check(fmap2, "fmap2"); _check(coords, "coords"); _check(corr_grad, "corr_grad")
+    _check(fmap1, "fmap1", fmap2, "fmap2", coords, "coords", corr_grad, "corr_grad")
     B, S, H1, W1, _ = coords.shape
     _, H2, W2, C = fmap2.shape
     fmap1_grad = torch.empty_like(fmap1)
