@@ -49,6 +49,51 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return v;
 }
 
+// ---- packed int16 pairs (x low, y high): one v_pk_min_i16 / v_pk_max_i16 serves both axes
+typedef short __attribute__((ext_vector_type(2))) short2v;
+
+__device__ __forceinline__ int pk16(int x, int y) { return (x & 0xffff) | (y << 16); }
+__device__ __forceinline__ int pk_lo(int v) { return (int)(short)(v & 0xffff); }
+__device__ __forceinline__ int pk_hi(int v) { return v >> 16; }
+__device__ __forceinline__ int pk_min(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ int pk_max(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Wave-wide packed min/max: DPP inside each row of 16 lanes (xor 1, xor 2, half-mirror,
+// mirror), then the four row results are read with v_readlane and combined (wave-uniform).
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_pk_reduce(int v) {
+#define LGU_DPP_STEP(ctrl)                                                  \
+  {                                                                         \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false); \
+    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                               \
+  }
+  LGU_DPP_STEP(0xB1)   // quad_perm:[1,0,3,2]
+  LGU_DPP_STEP(0x4E)   // quad_perm:[2,3,0,1]
+  LGU_DPP_STEP(0x141)  // row_half_mirror
+  LGU_DPP_STEP(0x140)  // row_mirror
+#undef LGU_DPP_STEP
+  const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return IS_MIN ? pk_min(pk_min(r0, r1), pk_min(r2, r3)) : pk_max(pk_max(r0, r1), pk_max(r2, r3));
+}
+
+// Sum over each row of 16 lanes (every lane of the row gets the row total).
+__device__ __forceinline__ float row16_sum(float v) {
+#define LGU_SUM_STEP(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+  LGU_SUM_STEP(0xB1)
+  LGU_SUM_STEP(0x4E)
+  LGU_SUM_STEP(0x141)
+  LGU_SUM_STEP(0x140)
+#undef LGU_SUM_STEP
+  return v;
+}
+
 inline int launch_status() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? LGU_OK : (int)e;

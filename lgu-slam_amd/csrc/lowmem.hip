@@ -266,6 +266,10 @@ __global__ __launch_bounds__(LM_WAVES * kWave) void altcorr_bwd_kernel(const flo
   }
 }
 
+// lowmem_tile.hip
+int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
+                         int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st);
+
 static int check_fmap_args(const void* a, const void* b, const void* c, const void* d, int B, int S, int H1, int W1,
                            int H2, int W2, int C, int radius) {
   if (!a || !b || !c || !d) return LGU_E_BADARG;
@@ -296,12 +300,17 @@ int lgu_lowmem_defsample_fwd_f32(const float* fmap1, const float* fmap2, const f
   if (rc != LGU_OK) return rc;
   if (!offset || (long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
   if (B == 0) return LGU_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // LGU_LOWMEM_VARIANT (debug/A-B only): 0 = tile-staged kernel, 1 = wave-per-pixel kernel
+  if (env_int("LGU_LOWMEM_VARIANT", 0) == 0) {
+    rc = lowmem_tile_dispatch(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
+    if (rc >= 0) return rc;
+  }
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int tiles = (W1 + LM_TP - 1) / LM_TP;
   const size_t lds = sizeof(float) * (size_t)S * nt * LM_PITCH;
   if (lds > 64 * 1024) return LGU_E_UNSUPPORTED;
   const unsigned grid = (unsigned)((size_t)B * H1 * tiles);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define CALL(QV)                                                                                                     \
   hipLaunchKernelGGL(lowmem_kernel<QV>, dim3(grid), dim3(LM_WAVES * kWave), lds, st, fmap1, fmap2, coords, offset, \
                      corr, B, S, H1, W1, H2, W2, C, radius, tiles)

@@ -1,0 +1,272 @@
+// lowmem_tile.hip — tile-staged on-the-fly deformable correlation (lowMem_defSample).
+//
+// Replaces offersample_LGS/lowMem_defSample.cu:27-134 for radius <= 3 (the production case).
+//
+// dot(fmap1[p], bilerp(fmap2)(x,y)) == bilerp over the four corners of dot(fmap1[p], fmap2[corner]):
+// a pixel's 49 taps only ever touch the integer positions inside its tap box (<= 16x16 for
+// |offset| < 4, r = 3), so the kernel builds that LOCAL correlation patch
+//     D_p[y2][x2] = sum_c fmap1[p][c] * fmap2[y2][x2][c]
+// once per pixel and then samples it exactly like the volume path.  Neighbouring pixels'
+// boxes overlap almost entirely, which the reference (one thread per pixel, 49*4*C global
+// loads each) and a wave-per-pixel kernel cannot exploit.  Here a workgroup owns a 4x16
+// pixel tile:
+//   0. every wave finds the tap boxes of its 8 pixels (packed DPP reduction); their union
+//      is the tile's staging window;
+//   1. per 8-channel chunk the window is staged in LDS ONCE (16-byte coalesced loads, 48-byte
+//      position pitch = conflict-free ds_read_b128 with lanes = positions) and every pixel
+//      accumulates its <= 256 patch entries from it: lanes = patch positions, fmap1[p] chunk in
+//      SGPRs (v_fma with a scalar operand), 4 accumulators per lane per pixel;
+//   2. the patch goes through a per-wave LDS scratch, the 49 taps blend their corners with
+//      per-corner zero padding (lowMem_defSample.cu:102-117) and park the result in a
+//      [tap][pixel] tile that is written out with 64-byte segments.
+// fmap2 traffic per pixel drops from 49*4*512 B to (window/64 pixels)*512 B; LDS reads and
+// fp32 FMAs (32.8 k per pixel-level at full boxes) become the bound.
+// Tiles whose window exceeds the LDS budget, and pixels whose box exceeds 256 positions,
+// take a per-tap fallback (lanes = taps, sequential channels) — correct for any offsets.
+// Channel sums run sequentially with FMA per position; the reference sums 32-channel chunks
+// of pre-blended values: equal to fp32 rounding (tests: 1e-5).
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+constexpr int LT_W = 16, LT_H = 4, LT_PIX = LT_W * LT_H;
+constexpr int LT_WAVES = 8, LT_PPW = LT_PIX / LT_WAVES;  // 8 pixels per wave
+constexpr int LT_CH = 8;                                  // channels per staged chunk
+constexpr int LT_PITCH = 12;                              // floats per staged position (48 B)
+constexpr int LT_MAXPOS = 1440;                           // staged positions (69 120 B)
+constexpr int LT_MAXBOX = 4 * kWave;                      // patch entries per pixel
+constexpr int LT_OUTP = LT_PIX + 1;
+
+__device__ __forceinline__ size_t lt_smem_floats() { return (size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8; }
+
+template <int R>
+__global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const float* __restrict__ fmap1,
+                                                                       const float* __restrict__ fmap2,
+                                                                       const float* __restrict__ coords, float* offset,
+                                                                       float* __restrict__ corr, int B, int S, int H1,
+                                                                       int W1, int H2, int W2, int C, int tiles_x,
+                                                                       int tiles_y) {
+  constexpr int RD = 2 * R + 1, NT = RD * RD;
+  extern __shared__ float4 smem4[];
+  float* const stage = reinterpret_cast<float*>(smem4);       // [LT_MAXPOS][LT_PITCH]
+  float* const dscr = stage + LT_MAXPOS * LT_PITCH;           // [LT_WAVES][LT_MAXBOX]
+  int* const pbox = reinterpret_cast<int*>(dscr + LT_WAVES * LT_MAXBOX);  // [LT_PIX][4] xlo,ylo,bw,bh
+  int* const ubox = pbox + LT_PIX * 4;                        // xmin,ymin,xmax,ymax of the tile window
+  float* const outt = stage;                                  // [NT][LT_OUTP], aliases the stage after the chunk loop
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int n = blockIdx.y;
+  const size_t HW1 = (size_t)H1 * W1;
+  const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
+  float* const obase = offset + (size_t)(b * n) * HW1 * NT * 2;
+
+  const bool tap = lane < NT;
+  const int ix = lane / RD, iy = lane - ix * RD;  // offset / output index [ix][iy]
+  const bool centre = (ix == R) && (iy == R);
+
+  if (tid == 0) { ubox[0] = 0x7fffffff; ubox[1] = 0x7fffffff; ubox[2] = -1; ubox[3] = -1; }
+  __syncthreads();
+
+  // ---- phase 0: sample positions and tap boxes of this wave's pixels ----
+  float xs[LT_PPW], ys[LT_PPW];
+#pragma unroll
+  for (int k = 0; k < LT_PPW; k++) {
+    const int pw = w * LT_PPW + k;
+    const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+    const bool pv = h1 < H1 && w1 < W1;
+    xs[k] = ys[k] = 0.0f;
+    int lo = 0x7fff7fff, hi = (int)0x80008000;
+    if (pv) {
+      const size_t pix = (size_t)h1 * W1 + w1;
+      const float cx = coords[(((size_t)b * S + n) * HW1 + pix) * 2 + 0];
+      const float cy = coords[(((size_t)b * S + n) * HW1 + pix) * 2 + 1];
+      float2 o = make_float2(0.f, 0.f);
+      if (tap) {
+        float2* op = reinterpret_cast<float2*>(obase + pix * NT * 2) + lane;
+        if (centre) *op = make_float2(0.f, 0.f);  // :80-81
+        else o = *op;
+      }
+      xs[k] = cx + o.x;  // :82-83
+      ys[k] = cy + o.y;
+      const int w2 = (int)floorf(xs[k]) - R + ix, h2 = (int)floorf(ys[k]) - R + iy;
+      const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
+      const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
+      const bool part = tap && xa <= xb && ya <= yb;  // at least one corner in bounds
+      lo = part ? pk16(xa, ya) : lo;
+      hi = part ? pk16(xb, yb) : hi;
+    }
+    lo = wave_pk_reduce<true>(lo);
+    hi = wave_pk_reduce<false>(hi);
+    const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
+    const bool any = pv && xhi >= xlo && yhi >= ylo;
+    if (lane == 0) {
+      pbox[pw * 4 + 0] = xlo; pbox[pw * 4 + 1] = ylo;
+      pbox[pw * 4 + 2] = any ? xhi - xlo + 1 : 0;
+      pbox[pw * 4 + 3] = any ? yhi - ylo + 1 : 0;
+      if (any && (xhi - xlo + 1) * (yhi - ylo + 1) <= LT_MAXBOX) {  // oversize boxes use the fallback, keep them out of the window
+        atomicMin(&ubox[0], xlo); atomicMin(&ubox[1], ylo);
+        atomicMax(&ubox[2], xhi); atomicMax(&ubox[3], yhi);
+      }
+    }
+  }
+  __syncthreads();
+  const int UX0 = ubox[0], UY0 = ubox[1];
+  const int UW = ubox[2] - UX0 + 1, UH = ubox[3] - UY0 + 1;
+  const bool have_window = ubox[2] >= 0;
+  const int npos = have_window ? UW * UH : 0;
+  const bool tiled = have_window && npos <= LT_MAXPOS;  // workgroup-uniform
+
+  float acc[LT_PPW][4];
+  int lofs[LT_PPW][4];  // float offset of this lane's patch entry inside the stage, -1 = none
+#pragma unroll
+  for (int k = 0; k < LT_PPW; k++) {
+    const int pw = w * LT_PPW + k;
+    const int xlo = pbox[pw * 4 + 0], ylo = pbox[pw * 4 + 1], bw = pbox[pw * 4 + 2], bh = pbox[pw * 4 + 3];
+    const int nb = bw * bh;
+    const float rbw = 1.0f / (float)(bw > 0 ? bw : 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      acc[k][j] = 0.0f;
+      const int q = lane + j * kWave;
+      const int qy = (int)(((float)q + 0.5f) * rbw);
+      const int qx = q - qy * bw;
+      lofs[k][j] = (tiled && nb <= LT_MAXBOX && q < nb) ? ((ylo + qy - UY0) * UW + (xlo + qx - UX0)) * LT_PITCH : -1;
+    }
+  }
+
+  // ---- phase 1: stage the window chunk by chunk, accumulate every pixel's patch ----
+  if (tiled) {
+    const float rUW = 1.0f / (float)UW;
+    for (int c0 = 0; c0 < C; c0 += LT_CH) {
+      __syncthreads();  // previous chunk fully consumed
+      for (int idx = tid; idx < npos * 2; idx += LT_WAVES * kWave) {
+        const int pos = idx >> 1, half = idx & 1;
+        const int uy = (int)(((float)pos + 0.5f) * rUW);
+        const int ux = pos - uy * UW;
+        const float4 v = *reinterpret_cast<const float4*>(F2 + ((size_t)(UY0 + uy) * W2 + (UX0 + ux)) * C + c0 + half * 4);
+        *reinterpret_cast<float4*>(stage + pos * LT_PITCH + half * 4) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < LT_PPW; k++) {
+        const int pw = w * LT_PPW + k;
+        const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+        if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
+        const float* f1p = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c0;  // wave-uniform -> scalar loads
+        float f1[LT_CH];
+#pragma unroll
+        for (int i = 0; i < LT_CH; i++) f1[i] = f1p[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (lofs[k][j] >= 0) {
+            const float4 a0 = *reinterpret_cast<const float4*>(stage + lofs[k][j]);
+            const float4 a1 = *reinterpret_cast<const float4*>(stage + lofs[k][j] + 4);
+            float s = acc[k][j];
+            s = __builtin_fmaf(f1[0], a0.x, s); s = __builtin_fmaf(f1[1], a0.y, s);
+            s = __builtin_fmaf(f1[2], a0.z, s); s = __builtin_fmaf(f1[3], a0.w, s);
+            s = __builtin_fmaf(f1[4], a1.x, s); s = __builtin_fmaf(f1[5], a1.y, s);
+            s = __builtin_fmaf(f1[6], a1.z, s); s = __builtin_fmaf(f1[7], a1.w, s);
+            acc[k][j] = s;
+          }
+        }
+      }
+    }
+    __syncthreads();  // the stage is dead from here on: it becomes the output tile
+  }
+
+  // ---- phase 2: sample every pixel's patch (or fall back to per-tap dots) ----
+  float* const D = dscr + w * LT_MAXBOX;
+#pragma unroll
+  for (int k = 0; k < LT_PPW; k++) {
+    const int pw = w * LT_PPW + k;
+    const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+    if (h1 >= H1 || w1 >= W1) continue;
+    const int xlo = pbox[pw * 4 + 0], ylo = pbox[pw * 4 + 1], bw = pbox[pw * 4 + 2], bh = pbox[pw * 4 + 3];
+    const float fxs = floorf(xs[k]), fys = floorf(ys[k]);
+    const float dx = xs[k] - fxs, dy = ys[k] - fys;  // :87-88
+    const int w2 = (int)fxs - R + ix, h2 = (int)fys - R + iy;
+    const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
+    const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
+    float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+    if (tiled && bw * bh <= LT_MAXBOX) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (lane + j * kWave < bw * bh) D[lane + j * kWave] = acc[k][j];
+      __builtin_amdgcn_wave_barrier();
+      if (tap) {
+        const int o = (h2 - ylo) * bw + (w2 - xlo);
+        if (b11) q11 = D[o];
+        if (b21) q21 = D[o + 1];
+        if (b12) q12 = D[o + bw];
+        if (b22) q22 = D[o + bw + 1];
+      }
+    } else if (tap) {
+      // fallback: this lane's four corner dots, channels in order
+      const float* f1p = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C;
+      const float* p11 = F2 + ((ptrdiff_t)h2 * W2 + w2) * C;
+      for (int c = 0; c < C; c += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(f1p + c);
+#define LGU_DOT4(acc_, ptr_)                                                         \
+  {                                                                                  \
+    const float4 v_ = *reinterpret_cast<const float4*>(ptr_);                        \
+    acc_ = __builtin_fmaf(f.x, v_.x, acc_); acc_ = __builtin_fmaf(f.y, v_.y, acc_); \
+    acc_ = __builtin_fmaf(f.z, v_.z, acc_); acc_ = __builtin_fmaf(f.w, v_.w, acc_); \
+  }
+        if (b11) LGU_DOT4(q11, p11 + c)
+        if (b21) LGU_DOT4(q21, p11 + C + c)
+        if (b12) LGU_DOT4(q12, p11 + (size_t)W2 * C + c)
+        if (b22) LGU_DOT4(q22, p11 + (size_t)W2 * C + C + c)
+#undef LGU_DOT4
+      }
+    }
+    if (tap) outt[lane * LT_OUTP + pw] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
+  }
+  __syncthreads();
+
+  // ---- write-out: corr[b][n][ix][iy][h1][w1], 16 pixels (64 B) per (tap, row) ----
+  for (int idx = tid; idx < NT * LT_PIX; idx += LT_WAVES * kWave) {
+    const int t = idx >> 6, pw = idx & (LT_PIX - 1);
+    const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+    if (h1 < H1 && w1 < W1) corr[((((size_t)b * S + n) * NT + t) * H1 + h1) * W1 + w1] = outt[t * LT_OUTP + pw];
+  }
+}
+
+template <int R>
+static int launch_tile(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
+                       int S, int H1, int W1, int H2, int W2, int C, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8);
+  auto kern = lowmem_tile_kernel<R>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int tiles_x = (W1 + LT_W - 1) / LT_W, tiles_y = (H1 + LT_H - 1) / LT_H;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * tiles_x * tiles_y), (unsigned)S), dim3(LT_WAVES * kWave), lds, st,
+                     fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, tiles_x, tiles_y);
+  return launch_status();
+}
+
+// Called from lgu_lowmem_defsample_fwd_f32 (lowmem.hip).  Returns -1 when this kernel does
+// not serve the arguments (the caller then uses the wave-per-pixel kernel).
+int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
+                         int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
+  if (radius < 1 || radius > 3 || C % LT_CH != 0 || !aligned || S > 65535) return -1;
+  switch (radius) {
+    case 1: return launch_tile<1>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+    case 2: return launch_tile<2>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+    default: return launch_tile<3>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+  }
+}
+
+}  // namespace lgu

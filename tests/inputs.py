@@ -40,7 +40,7 @@ def pyramid_case(seed, E, H1, W1, L, radius=3, sigma=3.0, off_scale=4.0, dense_o
     return dict(volumes=vols, coords=coords, offsets=offs)
 
 
-def fmap_case(seed, B, S, H1, W1, H2, W2, C, radius, sigma=3.0, scale_down=1.0, n_offset=None):
+def fmap_case(seed, B, S, H1, W1, H2, W2, C, radius, sigma=3.0, scale_down=1.0, n_offset=None, off_scale=4.0):
     rng = np.random.default_rng(seed)
     rd = 2 * radius + 1
     f1 = (rng.standard_normal((B, H1, W1, C)) * 0.5 / 4).astype(np.float32)
@@ -49,5 +49,5 @@ def fmap_case(seed, B, S, H1, W1, H2, W2, C, radius, sigma=3.0, scale_down=1.0, 
     c = np.stack([xs, ys], -1)[None, None].repeat(B, 0).repeat(S, 1)  # (B,S,H1,W1,2)
     c = ((c + rng.standard_normal(c.shape) * sigma) * scale_down).astype(np.float32)
     no = B if n_offset is None else n_offset
-    off = (4 * np.tanh(rng.standard_normal((no, H1, W1, rd, rd, 2)))).astype(np.float32)
+    off = (off_scale * np.tanh(rng.standard_normal((no, H1, W1, rd, rd, 2)))).astype(np.float32)
     return dict(fmap1=f1, fmap2=f2, coords=c, offset=off)

@@ -220,25 +220,41 @@ def test_gaussian_mask_forward_backward(lgu, oracle, shape):
 
 
 LOWMEM_CASES = [
-    # B, S, H1, W1, H2, W2, C, radius, sigma, scale
-    (3, 1, 12, 16, 12, 16, 128, 3, 3.0, 1.0),
-    (2, 1, 12, 16, 6, 8, 128, 3, 3.0, 0.5),
-    (2, 1, 15, 20, 7, 10, 64, 3, 6.0, 0.5),     # ragged: W1 = 20, odd H2/W2 as in 60x80 level 3
-    (1, 2, 8, 16, 8, 16, 32, 1, 3.0, 1.0),      # S = 2 uses offset[b*n]
+    # B, S, H1, W1, H2, W2, C, radius, sigma, scale, off_scale
+    (3, 1, 12, 16, 12, 16, 128, 3, 3.0, 1.0, 4.0),
+    (2, 1, 12, 16, 6, 8, 128, 3, 3.0, 0.5, 4.0),
+    (2, 1, 15, 20, 7, 10, 64, 3, 6.0, 0.5, 4.0),     # ragged: W1 = 20, odd H2/W2 as in 60x80 level 3
+    (1, 2, 8, 16, 8, 16, 32, 1, 3.0, 1.0, 4.0),      # S = 2 uses offset[b*n]
+    (2, 1, 60, 80, 60, 80, 128, 3, 3.0, 1.0, 4.0),   # BASELINE config 4 level-0 shape
+    (1, 1, 60, 80, 30, 40, 128, 3, 3.0, 0.5, 4.0),   # level 1
+    (1, 1, 24, 32, 24, 32, 64, 3, 3.0, 1.0, 14.0),   # boxes > 256 positions: per-pixel fallback
+    (1, 1, 60, 80, 60, 80, 32, 3, 40.0, 1.0, 4.0),   # scattered coords: tile window > LDS budget, per-tap fallback
+    (1, 1, 12, 16, 12, 16, 40, 2, 3.0, 1.0, 3.0),    # radius 2, C = 40 (C % 8 == 0, C % 32 != 0 is rejected by the ABI)
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("cfg", LOWMEM_CASES)
-def test_lowmem_defsample(lgu, oracle, cfg):
-    B, S, H1, W1, H2, W2, C, radius, sigma, scale = cfg
-    case = inputs.fmap_case(40 + H2, B, S, H1, W1, H2, W2, C, radius, sigma, scale)
-    o_ref = case["offset"].copy()
-    want, = oracle.lowMem_defSample(case["fmap1"], case["fmap2"], case["coords"], o_ref, radius)
-    o_dev = dev(case["offset"])
-    got, = lgu.ops.lowMem_defSample(dev(case["fmap1"]), dev(case["fmap2"]), dev(case["coords"]), o_dev, radius)
-    assert got.shape == want.shape
-    assert np.abs(host(got) - want).max() <= 1e-5
-    assert np.array_equal(host(o_dev), o_ref)  # edge-0 centre zeroed (b*n indexing), rest untouched
+def test_lowmem_defsample(lgu, oracle, cfg, variant):
+    B, S, H1, W1, H2, W2, C, radius, sigma, scale, osc = cfg
+    if C % 32 != 0:
+        with pytest.raises(lgu._lib.UnsupportedShape):
+            lgu.ops.lowMem_defSample(torch.zeros(B, H1, W1, C, device="cuda"), torch.zeros(B, H2, W2, C, device="cuda"),
+                                     torch.zeros(B, S, H1, W1, 2, device="cuda"),
+                                     torch.zeros(B, H1, W1, 2 * radius + 1, 2 * radius + 1, 2, device="cuda"), radius)
+        return
+    os.environ["LGU_LOWMEM_VARIANT"] = str(variant)
+    try:
+        case = inputs.fmap_case(40 + H2, B, S, H1, W1, H2, W2, C, radius, sigma, scale, off_scale=osc)
+        o_ref = case["offset"].copy()
+        want, = oracle.lowMem_defSample(case["fmap1"], case["fmap2"], case["coords"], o_ref, radius)
+        o_dev = dev(case["offset"])
+        got, = lgu.ops.lowMem_defSample(dev(case["fmap1"]), dev(case["fmap2"]), dev(case["coords"]), o_dev, radius)
+        assert got.shape == want.shape
+        assert np.abs(host(got) - want).max() <= 1e-5
+        assert np.array_equal(host(o_dev), o_ref)  # edge-0 centre zeroed (b*n indexing), rest untouched
+    finally:
+        os.environ.pop("LGU_LOWMEM_VARIANT", None)
 
 
 @pytest.mark.parametrize("cfg", [(3, 1, 12, 16, 6, 8, 128, 1, 3.0, 0.5), (2, 2, 8, 16, 8, 16, 64, 3, 5.0, 1.0),
