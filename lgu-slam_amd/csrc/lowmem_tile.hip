@@ -14,8 +14,8 @@
 //      is the tile's staging window;
 //   1. per 8-channel chunk the window is staged in LDS ONCE (16-byte coalesced loads, 48-byte
 //      position pitch = conflict-free ds_read_b128 with lanes = positions) and every pixel
-//      accumulates its <= 256 patch entries from it: lanes = patch positions, fmap1[p] chunk in
-//      SGPRs (v_fma with a scalar operand), 4 accumulators per lane per pixel;
+//      accumulates its <= 256 patch entries from it: lanes = patch positions, fmap1[p] chunk as
+//      an LDS broadcast, 4 accumulators per lane per pixel;
 //   2. the patch goes through a per-wave LDS scratch, the 49 taps blend their corners with
 //      per-corner zero padding (lowMem_defSample.cu:102-117) and park the result in a
 //      [tap][pixel] tile that is written out with 64-byte segments.
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   float* const dscr = stage + LT_MAXPOS * LT_PITCH;           // [LT_WAVES][LT_MAXBOX]
   int* const pbox = reinterpret_cast<int*>(dscr + LT_WAVES * LT_MAXBOX);  // [LT_PIX][4] xlo,ylo,bw,bh
   int* const ubox = pbox + LT_PIX * 4;                        // xmin,ymin,xmax,ymax of the tile window
+  float* const f1s = reinterpret_cast<float*>(ubox + 8);      // [LT_PIX][LT_CH] fmap1 chunk of the tile's pixels
   float* const outt = stage;                                  // [NT][LT_OUTP], aliases the stage after the chunk loop
 
   const int tid = threadIdx.x;
@@ -147,6 +148,14 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
     const float rUW = 1.0f / (float)UW;
     for (int c0 = 0; c0 < C; c0 += LT_CH) {
       __syncthreads();  // previous chunk fully consumed
+      if (tid < LT_PIX * 2) {  // this chunk of fmap1 for the tile's 64 pixels (read back as LDS broadcasts)
+        const int pw = tid >> 1, half = tid & 1;
+        const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h1 < H1 && w1 < W1)
+          v = *reinterpret_cast<const float4*>(fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c0 + half * 4);
+        *reinterpret_cast<float4*>(f1s + pw * LT_CH + half * 4) = v;
+      }
       for (int idx = tid; idx < npos * 2; idx += LT_WAVES * kWave) {
         const int pos = idx >> 1, half = idx & 1;
         const int uy = (int)(((float)pos + 0.5f) * rUW);
@@ -160,10 +169,9 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
         const int pw = w * LT_PPW + k;
         const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
         if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
-        const float* f1p = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c0;  // wave-uniform -> scalar loads
-        float f1[LT_CH];
-#pragma unroll
-        for (int i = 0; i < LT_CH; i++) f1[i] = f1p[i];
+        const float4 fa = *reinterpret_cast<const float4*>(f1s + pw * LT_CH);      // same address in every lane:
+        const float4 fb = *reinterpret_cast<const float4*>(f1s + pw * LT_CH + 4);  // LDS broadcast
+        const float f1[LT_CH] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           if (lofs[k][j] >= 0) {
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
 template <int R>
 static int launch_tile(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
                        int S, int H1, int W1, int H2, int W2, int C, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8);
+  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8 + LT_PIX * LT_CH);
   auto kern = lowmem_tile_kernel<R>;
   static bool attr_set = false;
   if (!attr_set) {

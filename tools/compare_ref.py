@@ -92,6 +92,7 @@ def main():
     base = torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, device=dev)
     off0 = (4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device=dev))).contiguous()
     tot_ref = tot_our = tot_old = 0.0
+    per_level = []
     worst = 0.0
     for l in range(4):
         f2 = (torch.randn(B, H >> l, W >> l, C, device=dev) * 0.125).contiguous()
@@ -100,7 +101,9 @@ def main():
         b, = ops.lowMem_defSample(f1, f2, cl, off0.clone(), 3)
         worst = max(worst, float((a - b).abs().max()))
         tot_ref += timeit(lambda: ref.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
-        tot_our += timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
+        t_l = timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
+        per_level.append(t_l)
+        tot_our += t_l
         os.environ["LGU_LOWMEM_VARIANT"] = "1"
         tot_old += timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
         os.environ.pop("LGU_LOWMEM_VARIANT")
@@ -111,7 +114,7 @@ def main():
                               "ref_ms": timeit(lambda: alt.altcorr_forward(f1, f2, cl, 1), iters=5, warm=1),
                               "ours_ms": timeit(lambda: ops.altcorr_forward(f1, f2, cl, 1), iters=5, warm=1)}))
     print(json.dumps({"op": "lowMem_defSample 4 levels B=16 60x80 C=128", "max_abs_diff_vs_reference": worst,
-                      "ref_ms": tot_ref, "ours_ms": tot_our, "ours_wave_per_pixel_ms": tot_old, "speedup": tot_ref / tot_our,
+                      "ref_ms": tot_ref, "ours_ms": tot_our, "ours_wave_per_pixel_ms": tot_old, "ours_ms_per_level": per_level, "speedup": tot_ref / tot_our,
                       "ours_Mpix_edges_per_s": B * H * W / tot_our / 1e3}))
 
 
