@@ -326,12 +326,18 @@ int lgu_altcorr_fwd_f32(const float* fmap1, const float* fmap2, const float* coo
   if (rc != LGU_OK) return rc;
   if (radius > 3) return LGU_E_UNSUPPORTED;  // lattice (rd+1)^2 must fit one wave
   if (B == 0) return LGU_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // altcorr_forward == lowMem_defSample with zero offsets (same per-corner zero padding, same
+  // [ix][iy] channel order): the tile-staged kernel serves it with a null offset pointer
+  if (env_int("LGU_LOWMEM_VARIANT", 0) == 0 && radius >= 1) {
+    rc = lowmem_tile_dispatch(fmap1, fmap2, coords, nullptr, corr, B, S, H1, W1, H2, W2, C, radius, st);
+    if (rc >= 0) return rc;
+  }
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int tiles = (W1 + LM_TP - 1) / LM_TP;
   const size_t lds = sizeof(float) * (size_t)S * nt * LM_PITCH;
   if (lds > 64 * 1024) return LGU_E_UNSUPPORTED;
   const unsigned grid = (unsigned)((size_t)B * H1 * tiles);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define CALL(QV)                                                                                                  \
   hipLaunchKernelGGL(altcorr_fwd_kernel<QV>, dim3(grid), dim3(LM_WAVES * kWave), lds, st, fmap1, fmap2, coords, \
                      corr, B, S, H1, W1, H2, W2, C, radius, tiles)

@@ -30,12 +30,14 @@
 namespace lgu {
 
 constexpr int LT_W = 16, LT_H = 4, LT_PIX = LT_W * LT_H;
-constexpr int LT_WAVES = 8, LT_PPW = LT_PIX / LT_WAVES;  // 8 pixels per wave
-constexpr int LT_CH = 8;                                  // channels per staged chunk
-constexpr int LT_PITCH = 12;                              // floats per staged position (48 B)
-constexpr int LT_MAXPOS = 1440;                           // staged positions (69 120 B)
+constexpr int LT_WAVES = 16, LT_PPW = LT_PIX / LT_WAVES;  // 1024 threads, 4 pixels per wave, one workgroup per CU
+constexpr int LT_CH = 16;                                 // channels per staged chunk
+constexpr int LT_Q4 = LT_CH / 4;                          // float4 per staged position
+constexpr int LT_PITCH = LT_CH + 4;                       // floats per staged position (80 B: conflict-free b128 reads)
+constexpr int LT_MAXPOS = 1440;                           // staged positions (115 200 B)
 constexpr int LT_MAXBOX = 4 * kWave;                      // patch entries per pixel
 constexpr int LT_OUTP = LT_PIX + 1;
+constexpr int LT_SCMAX = 4;                               // chunks staged per barrier pair when the window is small
 
 __device__ __forceinline__ size_t lt_smem_floats() { return (size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8; }
 
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   float* const dscr = stage + LT_MAXPOS * LT_PITCH;           // [LT_WAVES][LT_MAXBOX]
   int* const pbox = reinterpret_cast<int*>(dscr + LT_WAVES * LT_MAXBOX);  // [LT_PIX][4] xlo,ylo,bw,bh
   int* const ubox = pbox + LT_PIX * 4;                        // xmin,ymin,xmax,ymax of the tile window
-  float* const f1s = reinterpret_cast<float*>(ubox + 8);      // [LT_PIX][LT_CH] fmap1 chunk of the tile's pixels
+  float* const f1s = reinterpret_cast<float*>(ubox + 8);      // [LT_PIX][SC*LT_CH] fmap1 chunk(s) of the tile's pixels
   float* const outt = stage;                                  // [NT][LT_OUTP], aliases the stage after the chunk loop
 
   const int tid = threadIdx.x;
@@ -66,8 +68,10 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   const int n = blockIdx.y;
   const size_t HW1 = (size_t)H1 * W1;
   const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  const float* F1 = fmap1 + (size_t)b * H1 * W1 * C;  // per-edge bases keep the 32-bit offsets below small
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
-  float* const obase = offset + (size_t)(b * n) * HW1 * NT * 2;
+  // offset == nullptr: plain (zero-offset) sampling = altcorr_forward (src/altcorr_kernel.cu:27-149)
+  float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
 
   const bool tap = lane < NT;
   const int ix = lane / RD, iy = lane - ix * RD;  // offset / output index [ix][iy]
@@ -77,30 +81,38 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   __syncthreads();
 
   // ---- phase 0: sample positions and tap boxes of this wave's pixels ----
-  float xs[LT_PPW], ys[LT_PPW];
+  float2 o0[LT_PPW], c0v[LT_PPW];
+#pragma unroll
+  for (int k = 0; k < LT_PPW; k++) {  // all loads first, then the reductions
+    const int pw = w * LT_PPW + k;
+    const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+    const bool pv = h1 < H1 && w1 < W1;
+    const size_t pix = pv ? (size_t)h1 * W1 + w1 : 0;
+    c0v[k] = reinterpret_cast<const float2*>(coords)[((size_t)b * S + n) * HW1 + pix];
+    o0[k] = make_float2(0.f, 0.f);
+    if (obase && pv && tap && !centre) o0[k] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[lane];
+  }
+  if (obase && centre) {
+#pragma unroll
+    for (int k = 0; k < LT_PPW; k++) {
+      const int pw = w * LT_PPW + k;
+      const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+      if (h1 < H1 && w1 < W1)
+        reinterpret_cast<float2*>(obase + ((size_t)h1 * W1 + w1) * NT * 2)[lane] = make_float2(0.f, 0.f);  // :80-81
+    }
+  }
 #pragma unroll
   for (int k = 0; k < LT_PPW; k++) {
     const int pw = w * LT_PPW + k;
     const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
     const bool pv = h1 < H1 && w1 < W1;
-    xs[k] = ys[k] = 0.0f;
     int lo = 0x7fff7fff, hi = (int)0x80008000;
-    if (pv) {
-      const size_t pix = (size_t)h1 * W1 + w1;
-      const float cx = coords[(((size_t)b * S + n) * HW1 + pix) * 2 + 0];
-      const float cy = coords[(((size_t)b * S + n) * HW1 + pix) * 2 + 1];
-      float2 o = make_float2(0.f, 0.f);
-      if (tap) {
-        float2* op = reinterpret_cast<float2*>(obase + pix * NT * 2) + lane;
-        if (centre) *op = make_float2(0.f, 0.f);  // :80-81
-        else o = *op;
-      }
-      xs[k] = cx + o.x;  // :82-83
-      ys[k] = cy + o.y;
-      const int w2 = (int)floorf(xs[k]) - R + ix, h2 = (int)floorf(ys[k]) - R + iy;
+    {
+      const float xs = c0v[k].x + o0[k].x, ys = c0v[k].y + o0[k].y;  // :82-83
+      const int w2 = (int)floorf(xs) - R + ix, h2 = (int)floorf(ys) - R + iy;
       const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
       const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
-      const bool part = tap && xa <= xb && ya <= yb;  // at least one corner in bounds
+      const bool part = pv && tap && xa <= xb && ya <= yb;  // at least one corner in bounds
       lo = part ? pk16(xa, ya) : lo;
       hi = part ? pk16(xb, yb) : hi;
     }
@@ -126,63 +138,98 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   const bool tiled = have_window && npos <= LT_MAXPOS;  // workgroup-uniform
 
   float acc[LT_PPW][4];
-  int lofs[LT_PPW][4];  // float offset of this lane's patch entry inside the stage, -1 = none
+  unsigned lpos[LT_PPW][2];  // stage position of this lane's patch entries, two 16-bit fields each, 0xffff = none
 #pragma unroll
   for (int k = 0; k < LT_PPW; k++) {
     const int pw = w * LT_PPW + k;
     const int xlo = pbox[pw * 4 + 0], ylo = pbox[pw * 4 + 1], bw = pbox[pw * 4 + 2], bh = pbox[pw * 4 + 3];
     const int nb = bw * bh;
     const float rbw = 1.0f / (float)(bw > 0 ? bw : 1);
+    lpos[k][0] = lpos[k][1] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       acc[k][j] = 0.0f;
       const int q = lane + j * kWave;
       const int qy = (int)(((float)q + 0.5f) * rbw);
       const int qx = q - qy * bw;
-      lofs[k][j] = (tiled && nb <= LT_MAXBOX && q < nb) ? ((ylo + qy - UY0) * UW + (xlo + qx - UX0)) * LT_PITCH : -1;
+      const unsigned ps = (tiled && nb <= LT_MAXBOX && q < nb) ? (unsigned)((ylo + qy - UY0) * UW + (xlo + qx - UX0)) : 0xffffu;
+      lpos[k][j >> 1] |= ps << (16 * (j & 1));
     }
   }
 
   // ---- phase 1: stage the window chunk by chunk, accumulate every pixel's patch ----
   if (tiled) {
     const float rUW = 1.0f / (float)UW;
-    for (int c0 = 0; c0 < C; c0 += LT_CH) {
+    // small windows (coarse pyramid levels): stage SC chunks per barrier pair
+    int SC = 1;
+    if (npos * 4 <= LT_MAXPOS && C % (LT_CH * 4) == 0) SC = 4;
+    else if (npos * 2 <= LT_MAXPOS && C % (LT_CH * 2) == 0) SC = 2;
+    const int nvp = npos * SC;  // virtual positions: (sub-chunk, position)
+    const float rnpos = 1.0f / (float)npos;
+    // each thread's share of the window (chunk-invariant): source offsets relative to F2 + c0.
+    // The NEXT chunk's global loads are issued before the current chunk's FMAs (register
+    // prefetch), so only the LDS write sits between the two barriers.
+    constexpr int NPRE = (LT_MAXPOS * LT_Q4 + LT_WAVES * kWave - 1) / (LT_WAVES * kWave);
+    int soff[NPRE];
+    float4 pre[NPRE], pf1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int f1off = -1;
+    if (tid < LT_PIX * LT_Q4 * SC) {  // fmap1 chunk(s) of the tile's 64 pixels (read back as LDS broadcasts)
+      const int pw = tid / (LT_Q4 * SC);
+      const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+      if (h1 < H1 && w1 < W1) f1off = (h1 * W1 + w1) * C + (tid - pw * LT_Q4 * SC) * 4;
+    }
+    if (f1off >= 0) pf1 = *reinterpret_cast<const float4*>(F1 + f1off);
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) {
+      const int idx = tid + i * LT_WAVES * kWave;
+      const int vp = idx / LT_Q4;
+      const int sc = (int)(((float)vp + 0.5f) * rnpos);
+      const int pos = vp - sc * npos;
+      const int uy = (int)(((float)pos + 0.5f) * rUW);
+      const int ux = pos - uy * UW;
+      soff[i] = idx < nvp * LT_Q4 ? ((UY0 + uy) * W2 + (UX0 + ux)) * C + sc * LT_CH + (idx % LT_Q4) * 4 : -1;
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (soff[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(F2 + soff[i]);  // chunk 0
+    }
+    const int cstep = LT_CH * SC;
+    for (int c0 = 0; c0 < C; c0 += cstep) {
       __syncthreads();  // previous chunk fully consumed
-      if (tid < LT_PIX * 2) {  // this chunk of fmap1 for the tile's 64 pixels (read back as LDS broadcasts)
-        const int pw = tid >> 1, half = tid & 1;
-        const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h1 < H1 && w1 < W1)
-          v = *reinterpret_cast<const float4*>(fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C + c0 + half * 4);
-        *reinterpret_cast<float4*>(f1s + pw * LT_CH + half * 4) = v;
-      }
-      for (int idx = tid; idx < npos * 2; idx += LT_WAVES * kWave) {
-        const int pos = idx >> 1, half = idx & 1;
-        const int uy = (int)(((float)pos + 0.5f) * rUW);
-        const int ux = pos - uy * UW;
-        const float4 v = *reinterpret_cast<const float4*>(F2 + ((size_t)(UY0 + uy) * W2 + (UX0 + ux)) * C + c0 + half * 4);
-        *reinterpret_cast<float4*>(stage + pos * LT_PITCH + half * 4) = v;
+      if (tid < LT_PIX * LT_Q4 * SC) *reinterpret_cast<float4*>(f1s + tid * 4) = pf1;
+#pragma unroll
+      for (int i = 0; i < NPRE; i++) {
+        const int idx = tid + i * LT_WAVES * kWave;
+        if (soff[i] >= 0) *reinterpret_cast<float4*>(stage + (idx / LT_Q4) * LT_PITCH + (idx % LT_Q4) * 4) = pre[i];
       }
       __syncthreads();
+      if (c0 + cstep < C) {
+        if (f1off >= 0) pf1 = *reinterpret_cast<const float4*>(F1 + f1off + c0 + cstep);
 #pragma unroll
-      for (int k = 0; k < LT_PPW; k++) {
-        const int pw = w * LT_PPW + k;
-        const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
-        if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
-        const float4 fa = *reinterpret_cast<const float4*>(f1s + pw * LT_CH);      // same address in every lane:
-        const float4 fb = *reinterpret_cast<const float4*>(f1s + pw * LT_CH + 4);  // LDS broadcast
-        const float f1[LT_CH] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+        for (int i = 0; i < NPRE; i++)
+          if (soff[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(F2 + soff[i] + c0 + cstep);
+      }
+      for (int sc = 0; sc < SC; sc++) {
+        const float* stg = stage + sc * npos * LT_PITCH;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (lofs[k][j] >= 0) {
-            const float4 a0 = *reinterpret_cast<const float4*>(stage + lofs[k][j]);
-            const float4 a1 = *reinterpret_cast<const float4*>(stage + lofs[k][j] + 4);
-            float s = acc[k][j];
-            s = __builtin_fmaf(f1[0], a0.x, s); s = __builtin_fmaf(f1[1], a0.y, s);
-            s = __builtin_fmaf(f1[2], a0.z, s); s = __builtin_fmaf(f1[3], a0.w, s);
-            s = __builtin_fmaf(f1[4], a1.x, s); s = __builtin_fmaf(f1[5], a1.y, s);
-            s = __builtin_fmaf(f1[6], a1.z, s); s = __builtin_fmaf(f1[7], a1.w, s);
-            acc[k][j] = s;
+        for (int k = 0; k < LT_PPW; k++) {
+          const int pw = w * LT_PPW + k;
+          const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+          if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
+          float4 f1[LT_Q4];  // same address in every lane: LDS broadcast
+#pragma unroll
+          for (int i = 0; i < LT_Q4; i++) f1[i] = *reinterpret_cast<const float4*>(f1s + (pw * SC + sc) * LT_CH + i * 4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned ps = (lpos[k][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (ps != 0xffffu) {
+              float s = acc[k][j];
+#pragma unroll
+              for (int i = 0; i < LT_Q4; i++) {
+                const float4 a = *reinterpret_cast<const float4*>(stg + ps * LT_PITCH + i * 4);
+                s = __builtin_fmaf(f1[i].x, a.x, s); s = __builtin_fmaf(f1[i].y, a.y, s);
+                s = __builtin_fmaf(f1[i].z, a.z, s); s = __builtin_fmaf(f1[i].w, a.w, s);
+              }
+              acc[k][j] = s;
+            }
           }
         }
       }
@@ -193,13 +240,24 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   // ---- phase 2: sample every pixel's patch (or fall back to per-tap dots) ----
   float* const D = dscr + w * LT_MAXBOX;
 #pragma unroll
+  for (int k = 0; k < LT_PPW; k++) {  // sample positions again (L2 hits; the centre was zeroed in phase 0)
+    const int pw = w * LT_PPW + k;
+    const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
+    const bool pv = h1 < H1 && w1 < W1;
+    const size_t pix = pv ? (size_t)h1 * W1 + w1 : 0;
+    c0v[k] = reinterpret_cast<const float2*>(coords)[((size_t)b * S + n) * HW1 + pix];
+    o0[k] = make_float2(0.f, 0.f);
+    if (obase && pv && tap && !centre) o0[k] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[lane];
+  }
+#pragma unroll
   for (int k = 0; k < LT_PPW; k++) {
     const int pw = w * LT_PPW + k;
     const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
     if (h1 >= H1 || w1 >= W1) continue;
     const int xlo = pbox[pw * 4 + 0], ylo = pbox[pw * 4 + 1], bw = pbox[pw * 4 + 2], bh = pbox[pw * 4 + 3];
-    const float fxs = floorf(xs[k]), fys = floorf(ys[k]);
-    const float dx = xs[k] - fxs, dy = ys[k] - fys;  // :87-88
+    const float xs = c0v[k].x + o0[k].x, ys = c0v[k].y + o0[k].y;
+    const float fxs = floorf(xs), fys = floorf(ys);
+    const float dx = xs - fxs, dy = ys - fys;  // :87-88
     const int w2 = (int)fxs - R + ix, h2 = (int)fys - R + iy;
     const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
     const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
@@ -251,7 +309,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
 template <int R>
 static int launch_tile(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
                        int S, int H1, int W1, int H2, int W2, int C, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8 + LT_PIX * LT_CH);
+  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8 + LT_PIX * LT_CH * LT_SCMAX);
   auto kern = lowmem_tile_kernel<R>;
   static bool attr_set = false;
   if (!attr_set) {
