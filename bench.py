@@ -169,10 +169,14 @@ def main():
     out = torch.empty(E, L * 49, H1, W1, device=dev)
     units = E * H1 * W1
 
+    # prepared launch: pointer tables built once, one ctypes call per step (the kernel is
+    # ~60 us; per-call Python argument handling would otherwise bound the loop)
+    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe)
+
     def step():
         # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful
         # offset[1] *= mask of corr.py:94-99 run inside the same launch
-        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=args.probe, out=out)
+        plan(coords, out=out)
 
     def barrier():
         if world > 1:
@@ -221,8 +225,8 @@ def main():
 
     if rank == 0:
         A, U = algorithmic_bytes_per_unit(vols, coords, offs, R)
-        kname = {0: "defcorr_gather_kernel", 1: "defcorr_pyr_kernel", 2: "defcorr_generic_kernel"}.get(args.variant, "?")
-        kname = "lgu::%s<3,%s,12>" % (kname, "true" if args.probe else "false") if args.variant != 2 else "lgu::" + kname
+        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2>", 3: "lgu::defcorr_gather_kernel<3,%s,12,4>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
+                 2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
         # because counters cannot be collected from inside the timed process; see profiles/.

@@ -149,11 +149,17 @@ class CorrBlock:
             offs.append(o.view(E, ht, wd, rd, rd, 2))
         pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
         # inference: probe + mask + all levels + concatenation in ONE launch; offset[1] is
-        # scaled in place by the kernel (the same persistent state as above)
+        # scaled in place by the kernel (the same persistent state as above).  The prepared
+        # launch is rebuilt only when the pyramid / offset buffers change (cat, __getitem__).
+        key = tuple(t.data_ptr() for t in pyr) + tuple(o.data_ptr() if o is not None else 0 for o in offs)
         try:
-            out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius, probe=True)
+            if getattr(self, "_plan_key", None) != key:
+                self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True)
+                self._plan_key = key
+            out = self._plan(coords)
         except _lib.UnsupportedShape:
             # shapes the fused probe does not serve (e.g. W2 % 4 != 0): separate probe ops
+            self._plan_key = None
             probe, = ops.corr_index_forward(pyr[1], (coords / 2).contiguous(), 1)
             self.offset[1] = (self.offset[1] * _uncertainty_mask(probe)).contiguous()
             offs[1] = self.offset[1].view(E, ht, wd, rd, rd, 2)

@@ -391,8 +391,9 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // CU's L1 for the other three corners.  Every load of the wave's 16 jobs is issued before
 // the first result is used.  Far fewer instructions per pixel than the LDS-DMA kernel; the
 // price is L1/TA work per corner instead of per line.
-template <int R, bool PROBE, int ZMASK>
-__global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const PyrParams p) {
+// GP = pixels per wave (TP / GP waves per workgroup)
+template <int R, bool PROBE, int ZMASK, int GP>
+__global__ __launch_bounds__((TP / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   constexpr int LAT = 2 * R + 2;
   constexpr int LATP = LAT <= 4 ? 4 : 8;
@@ -424,11 +425,11 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
   const size_t row_pix = ((size_t)e * p.H1 + y) * p.W1;
 
   // ---- phase 0: coords + offsets ----
-  float x0[PPW], y0[PPW];
-  float2 off[PPW][FASTL];
+  float x0[GP], y0[GP];
+  float2 off[GP][FASTL];
 #pragma unroll
-  for (int k = 0; k < PPW; k++) {
-    const int px = xbase + w * PPW + k;
+  for (int k = 0; k < GP; k++) {
+    const int px = xbase + w * GP + k;
     const bool pv = px < p.W1;
     x0[k] = pv ? p.coords[((size_t)e * 2 + 0) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
     y0[k] = pv ? p.coords[((size_t)e * 2 + 1) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
   }
   if (centre) {  // reference side effect (defCorrSample_kernel.cu:51-52)
 #pragma unroll
-    for (int k = 0; k < PPW; k++) {
-      const int px = xbase + w * PPW + k;
+    for (int k = 0; k < GP; k++) {
+      const int px = xbase + w * GP + k;
       if (px >= p.W1) continue;
 #pragma unroll
       for (int l = 0; l < FASTL; l++)
@@ -450,25 +451,25 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
           reinterpret_cast<float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane] = make_float2(0.0f, 0.0f);
     }
   }
-  float2 cs[PPW][FASTL];
+  float2 cs[GP][FASTL];
 #pragma unroll
   for (int l = 0; l < FASTL; l++) {
     const float sc = __builtin_ldexpf(1.0f, -(p.lbase + l));
 #pragma unroll
-    for (int k = 0; k < PPW; k++) cs[k][l] = make_float2(x0[k] * sc, y0[k] * sc);
+    for (int k = 0; k < GP; k++) cs[k][l] = make_float2(x0[k] * sc, y0[k] * sc);
   }
 
   // ---- phase A: issue every load.  Order: probe lattices first (the level-1 gathers wait
   // for them), then everything that does not depend on the probe, then level 1.
-  float platv[PPW];
-  float latv[PPW][FASTL];
-  float q[PPW][FASTL][4];
-  float gdx[PPW][FASTL], gdy[PPW][FASTL];
-  int gflag[PPW][FASTL];  // bit0 tap valid, bit1 x2 in bounds, bit2 y2 in bounds
+  float platv[GP];
+  float latv[GP][FASTL];
+  float q[GP][FASTL][4];
+  float gdx[GP][FASTL], gdy[GP][FASTL];
+  int gflag[GP][FASTL];  // bit0 tap valid, bit1 x2 in bounds, bit2 y2 in bounds
 #pragma unroll
-  for (int k = 0; k < PPW; k++) {
+  for (int k = 0; k < GP; k++) {
     platv[k] = 0.0f;
-    const int px = xbase + w * PPW + k;
+    const int px = xbase + w * GP + k;
     if (PROBE && px < p.W1) {
       const int H2 = p.H2[1], W2 = p.W2[1];
       const int X = (int)floorf(cs[k][1].x) - 1 + (lane & 3), Y = (int)floorf(cs[k][1].y) - 1 + ((lane >> 2) & 3);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
   }
 
   auto issue_level = [&](int k, int l) __attribute__((always_inline)) {
-    const int px = xbase + w * PPW + k;
+    const int px = xbase + w * GP + k;
     const bool pv = px < p.W1;
     const int H2 = p.H2[l], W2 = p.W2[l];
     const float ofsX = off[k][l].x + cs[k][l].x, ofsY = off[k][l].y + cs[k][l].y;  // :56-57
@@ -501,8 +502,8 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
   };
 
 #pragma unroll
-  for (int k = 0; k < PPW; k++) {
-    const int px = xbase + w * PPW + k;
+  for (int k = 0; k < GP; k++) {
+    const int px = xbase + w * GP + k;
     const bool pv = px < p.W1;
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
@@ -518,13 +519,13 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
           if (pv && lat_on && in_bounds(Y, X, H2, W2))
             latv[k][l] = p.vol[l][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
         } else if (k == 0) {
-          const int pxl = xbase + w * PPW + lpix;
+          const int pxl = xbase + w * GP + lpix;
           float cxl = cs[0][l].x, cyl = cs[0][l].y;
 #pragma unroll
-          for (int kk = 1; kk < PPW; kk++)
+          for (int kk = 1; kk < GP; kk++)
             if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
           const int X = (int)floorf(cxl) - R + lx, Y = (int)floorf(cyl) - R + ly;
-          if (pxl < p.W1 && lpix < PPW && lat_on && in_bounds(Y, X, H2, W2))
+          if (pxl < p.W1 && lpix < GP && lat_on && in_bounds(Y, X, H2, W2))
             latv[k][l] = p.vol[l][(row_pix + pxl) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
         }
       } else if (!(PROBE && l == 1)) {
@@ -536,8 +537,8 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
   // ---- probe -> mask -> level-1 offsets (corr.py:94-99), then the level-1 gathers ----
   if (PROBE) {
 #pragma unroll
-    for (int k = 0; k < PPW; k++) {
-      const int px = xbase + w * PPW + k;
+    for (int k = 0; k < GP; k++) {
+      const int px = xbase + w * GP + k;
       const bool pv = px < p.W1;
       const int H2 = p.H2[1], W2 = p.W2[1];
       const int pi = lane / 3, pj = lane - pi * 3;
@@ -563,8 +564,8 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
 
   // ---- phase B: blend, park in the transpose tile ----
 #pragma unroll
-  for (int k = 0; k < PPW; k++) {
-    const int px = xbase + w * PPW + k;
+  for (int k = 0; k < GP; k++) {
+    const int px = xbase + w * GP + k;
     const bool pv = px < p.W1;
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
@@ -575,9 +576,9 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
         float cxl = cs[k][l].x, cyl = cs[k][l].y;
         int pxl = px;
         if (PIXOP > 1) {
-          pxl = xbase + w * PPW + lpix;
+          pxl = xbase + w * GP + lpix;
 #pragma unroll
-          for (int kk = 1; kk < PPW; kk++)
+          for (int kk = 1; kk < GP; kk++)
             if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
         }
         const float q11 = __shfl(latv[k][l], lsrc, kWave), q21 = __shfl(latv[k][l], lsrc + 1, kWave);
@@ -587,8 +588,8 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
         const int x1 = (int)fxs - R + lti, y1 = (int)fys - R + ltj;
         float val = 0.0f;
         if (in_bounds(y1, x1, H2, W2)) val = bilerp(q11, q21, q12, q22, dx, dy);
-        if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < PPW))
-          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * OUT_PITCH + (w * PPW + (PIXOP == 1 ? k : lpix))] = val;
+        if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < GP))
+          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * OUT_PITCH + (w * GP + (PIXOP == 1 ? k : lpix))] = val;
         continue;
       }
       if (!pv) continue;
@@ -597,14 +598,14 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_gather_kernel(const Pyr
       const float q12 = (fl & 4) ? q[k][l][2] : 0.0f;
       const float q22 = ((fl & 6) == 6) ? q[k][l][3] : 0.0f;
       const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
-      if (tap) outst[(l * NT + lane) * OUT_PITCH + (w * PPW + k)] = val;
+      if (tap) outst[(l * NT + lane) * OUT_PITCH + (w * GP + k)] = val;
     }
   }
   __syncthreads();
 
   const int nout = p.L * NT * TP;
   float* const orow = p.out + (((size_t)e * p.Ctot + p.cbase) * p.H1 + y) * p.W1 + xbase;
-  for (int idx = threadIdx.x; idx < nout; idx += NWAVE * kWave) {
+  for (int idx = threadIdx.x; idx < nout; idx += (TP / GP) * kWave) {
     const int c = idx >> 4, pc = idx & (TP - 1);
     if (xbase + pc < p.W1) orow[(size_t)c * HW1 + pc] = outst[c * OUT_PITCH + pc];
   }
@@ -671,14 +672,16 @@ template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * OUT_PITCH;
-  auto kern = KIND == 0 ? defcorr_pyr_kernel<R, PROBE, ZMASK> : defcorr_gather_kernel<R, PROBE, ZMASK>;
+  auto kern = KIND == 0 ? defcorr_pyr_kernel<R, PROBE, ZMASK>
+                        : KIND == 1 ? defcorr_gather_kernel<R, PROBE, ZMASK, 4> : defcorr_gather_kernel<R, PROBE, ZMASK, 2>;
+  const int nthreads = KIND == 2 ? (TP / 2) * kWave : NWAVE * kWave;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const unsigned grid = (unsigned)((size_t)p.E * p.H1 * p.tiles_per_row);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVE * kWave), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, p);
   return launch_status();
 }
 
@@ -699,7 +702,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = register-gather kernel, 1 = LDS-DMA staged kernel, 2 = generic
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = register-gather kernel, 2 px/wave, 512-thread workgroups
+  // (production), 3 = the same with 4 px/wave, 1 = LDS-DMA staged kernel, 2 = generic
   // one-thread-per-output kernel (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
 
@@ -746,7 +750,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
 #define LGU_LAUNCH_K(PR, ZM, KD)                                                                   \
   (radius == 3 ? launch_fast<3, PR, ZM, KD>(p, st)                                                 \
                : radius == 2 ? launch_fast<2, PR, ZM, KD>(p, st) : launch_fast<1, PR, ZM, KD>(p, st))
-#define LGU_LAUNCH(PR, ZM) (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0) : LGU_LAUNCH_K(PR, ZM, 1))
+#define LGU_LAUNCH(PR, ZM) (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0) : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : LGU_LAUNCH_K(PR, ZM, 2))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
       else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
 #undef LGU_LAUNCH

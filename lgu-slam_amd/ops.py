@@ -190,3 +190,44 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
                                                      1 if probe else 0, _stream(coords))
     _lib.check(rc, "defcorr_pyramid_forward")
     return out
+
+
+class DefcorrPyramidPlan:
+    """Prepared launch of the fused pyramid sampler for a fixed pyramid / offset set: the
+    pointer and size tables are built once, a call costs one ctypes invocation.  Used by
+    CorrBlock (the pyramid is fixed between `cat`/`__getitem__` calls while `coords` changes
+    every update) and by bench.py so the step is not bound by Python argument handling.
+    """
+
+    def __init__(self, volumes, offsets, radius, probe=False):
+        L = len(volumes)
+        if len(offsets) != L:
+            raise RuntimeError("DefcorrPyramidPlan: need one offset entry (tensor or None) per level")
+        named = []
+        for l, v in enumerate(volumes):
+            named += [v, "volume[%d]" % l]
+            if offsets[l] is not None:
+                named += [offsets[l], "offset[%d]" % l]
+        _check(*named)
+        self._keep = (list(volumes), list(offsets))  # keep the buffers alive
+        self.L, self.radius, self.flags = L, radius, (1 if probe else 0)
+        self.E, self.H1, self.W1 = volumes[0].shape[:3]
+        self.device = volumes[0].device
+        self.channels = L * (2 * radius + 1) ** 2
+        self._vp = (_vp * L)(*[v.data_ptr() for v in volumes])
+        self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
+        self._h2 = (ctypes.c_int * L)(*[v.shape[3] for v in volumes])
+        self._w2 = (ctypes.c_int * L)(*[v.shape[4] for v in volumes])
+        self._fn = _lib.load().lgu_defcorr_pyramid_fwd_f32
+
+    def __call__(self, coords, out=None):
+        if tuple(coords.shape) != (self.E, 2, self.H1, self.W1):
+            raise RuntimeError("coords must be (E,2,H1,W1)")
+        _check(coords, "coords")
+        if out is None:
+            out = torch.empty((self.E, self.channels, self.H1, self.W1), dtype=torch.float32, device=self.device)
+        rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
+                      self._h2, self._w2, self.radius, self.flags,
+                      torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "defcorr_pyramid_forward")
+        return out

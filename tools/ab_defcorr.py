@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the fused-sampler kernel variants in ONE process on one device
+(cdna_hip_programming.md rule 24): N configs x M rounds, HIP-event time per launch, median/min."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import lgu_slam_amd  # noqa: E402
+
+ops = lgu_slam_amd.ops
+dev = torch.device("cuda:0")
+E, H1, W1, L, R = 20, 48, 64, 4, 3
+vols, coords, offs = bench.make_inputs(E, H1, W1, L, R, 1234, dev)
+out = torch.empty(E, 196, H1, W1, device=dev)
+configs = [dict(variant=v, nt=nt, probe=pr) for v in (0, 3, 1) for nt in (0, 1) for pr in (False, True)]
+configs = [c for c in configs if not (c["variant"] == 1 and c["nt"] == 1)]
+times = {i: [] for i in range(len(configs))}
+
+
+def run(c, iters):
+    os.environ["LGU_DEFCORR_VARIANT"] = str(c["variant"])
+    os.environ["LGU_DEFCORR_NT"] = str(c["nt"])
+    for _ in range(3):
+        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=c["probe"], out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=c["probe"], out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+for rnd in range(8):
+    for i, c in enumerate(configs):
+        times[i].append(run(c, 50))
+for i, c in enumerate(configs):
+    t = np.array(times[i])
+    print(json.dumps(dict(c, us_median=float(np.median(t)), us_min=float(t.min()),
+                          Mpix_edges_per_s=E * H1 * W1 / float(np.median(t)))))
