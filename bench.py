@@ -252,7 +252,7 @@ def main():
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": A * units,
                          "algorithmic_bytes_per_unit": A, "unique_volume_elements_per_unit": U,
                          "kernel": kname, "device_ms_per_step": dev_ms / args.steps},
-            "cpu_baseline": None if args.no_cpu else cpu_baseline(E, H1, W1, L, R),
+            "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(E, H1, W1, L, R),  # rank 0, N=1 only
         }
         if exchange:
             res["exchange"] = exchange
