@@ -100,6 +100,16 @@ int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords
                                 int L, int E, int H1, int W1, const int* H2, const int* W2,
                                 int radius, int flags, void* stream);
 
+/* Fused volume post-processing of CorrBlock.__init__ (reference droid_slam/gaussianMask_cuda.py:84-86
+ * and droid_slam/modules/corr.py:79-86): in ONE pass over the raw all-pairs volume
+ *   level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(covs.x*covs.y)) + volume
+ *   level l = avg_pool2d(level l-1, 2, stride 2) over the target dims, l = 1..L-1
+ * levels[l] (E,H1,W1,H2>>l,W2>>l) fully written; levels[0] may alias `volume` (in place).
+ * `levels` is a HOST array of L device pointers.  Requires W2 % 4 == 0 and a slice pyramid
+ * that fits LDS (<= 96 KiB); otherwise LGU_E_UNSUPPORTED and the caller composes the ops. */
+int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
 /* ---- low-memory (on-the-fly correlation) path ---------------------------------- */
 
 /* defCorrSample.lowMem_defSample        (droid.cpp:124-136, lowMem_defSample.cu:27-134,137-168).

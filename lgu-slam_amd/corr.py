@@ -106,16 +106,27 @@ class CorrBlock:
         self.offset, self._zero_level = generate_offsets(ofsMap, ofs_residual, feats, num_levels)
 
         self.t = feats.permute(0, 2, 3, 1).contiguous()
-        volume, mean_n, det = GA(self.t, volume)
+        needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(q.requires_grad for q in GA.parameters()))
+        self.corr_pyramid = None
+        if not needs_grad and hasattr(GA, "gaussian_parameters"):
+            # inference: Gaussian re-weighting, "/denominator + corr" and the 3 poolings in ONE
+            # pass over the volume, level 0 in place (ops.volume_pyramid)
+            mean_n, cov, det = GA.gaussian_parameters(self.t)
+            try:
+                self.corr_pyramid = ops.volume_pyramid(mean_n.float().contiguous(), cov, volume.contiguous(), num_levels,
+                                                       GA.RADIUS, inplace=True)
+            except _lib.UnsupportedShape:
+                self.corr_pyramid = None
+        if self.corr_pyramid is None:
+            volume, mean_n, det = GA(self.t, volume)
+            # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
+            self.corr_pyramid = []
+            lvl = volume.reshape(b * n * h * w, 1, h, w)
+            for i in range(num_levels):
+                self.corr_pyramid.append(lvl.view(b * n, h, w, h // 2 ** i, w // 2 ** i))
+                lvl = F.avg_pool2d(lvl, 2, stride=2)
         self.mean_n = mean_n.view(b, n, h, w, 2)
         self.theta = 2 * det.view(b, n, h, w)
-
-        # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
-        self.corr_pyramid = []
-        lvl = volume.reshape(b * n * h * w, 1, h, w)
-        for i in range(num_levels):
-            self.corr_pyramid.append(lvl.view(b * n, h, w, h // 2 ** i, w // 2 ** i))
-            lvl = F.avg_pool2d(lvl, 2, stride=2)
 
     # ---- lookup ----
     def __call__(self, coords):

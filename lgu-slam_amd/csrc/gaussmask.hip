@@ -132,6 +132,75 @@ __global__ __launch_bounds__(256) void gaussmask_bwd_kernel(const float* __restr
   }
 }
 
+
+// ---- fused volume post-processing ("next" row f1 of SURVEY.md §8) -----------------------
+// One pass over every level-0 slice replaces, per new edge, the reference's
+//   gaussianMask kernel + zeros_like memset            (gaussianAttn.cu:134-163)
+//   corr1 / (6.28*sqrt(det)) + corr                    (gaussianMask_cuda.py:85-86, 2 torch passes)
+//   3x avg_pool2d(2, stride 2) over the target dims    (corr.py:83-86)
+// i.e. ~100 KB of HBM traffic per pixel, with 12 KB read + 16 KB written: the slice is held in
+// LDS, re-weighted in place, written out as level 0 and pooled to levels 1..L-1 from LDS.
+// Arithmetic order follows the torch ops it replaces: t = (v*3*e)/den + v, pooled value =
+// (((a00 + a01) + a10) + a11) / 4 (ATen's avg_pool2d accumulation order).
+constexpr int VP_THREADS = 256;
+constexpr int VP_MAXL = 4;
+
+struct VolPyrParams {
+  const float* means;
+  const float* covs;
+  const float* vin;
+  float* out[VP_MAXL];  // out[0] may alias vin
+  size_t npix;
+  int H2, W2, L, r;
+};
+
+__global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyrParams p) {
+  extern __shared__ float4 vp_smem4[];
+  float* const sm = reinterpret_cast<float*>(vp_smem4);
+  const size_t pix = blockIdx.x;
+  const int H2 = p.H2, W2 = p.W2, HW2 = H2 * W2;
+  const float mx = p.means[pix * 2 + 0], my = p.means[pix * 2 + 1];
+  const float c1 = p.covs[pix * 2 + 0], c2 = p.covs[pix * 2 + 1];
+  const float den = 6.28f * sqrtf(c1 * c2);  // gaussianMask_cuda.py:79,85 (det = cov0*cov1)
+  const int cx = (int)floorf(mx), cy = (int)floorf(my);
+  const int xa = cx - p.r, xb = cx + p.r, ya = cy - p.r, yb = cy + p.r;
+  const float4* vin = reinterpret_cast<const float4*>(p.vin + pix * (size_t)HW2);
+  float4* vout = reinterpret_cast<float4*>(p.out[0] + pix * (size_t)HW2);
+  const int g_per_row = W2 >> 2;
+  for (int gi = threadIdx.x; gi < (HW2 >> 2); gi += VP_THREADS) {
+    const int row = gi / g_per_row;
+    const int x4 = (gi - row * g_per_row) << 2;
+    float4 v = vin[gi];
+    if (row >= ya && row <= yb && x4 + 3 >= xa && x4 <= xb) {
+      // inside the window: corr1 / denominator + corr; outside corr1 == 0 and the sum is v exactly
+      if (x4 + 0 >= xa && x4 + 0 <= xb) v.x = (v.x * 3.0f * gauss_e(x4 + 0, row, mx, my, c1, c2)) / den + v.x;
+      if (x4 + 1 >= xa && x4 + 1 <= xb) v.y = (v.y * 3.0f * gauss_e(x4 + 1, row, mx, my, c1, c2)) / den + v.y;
+      if (x4 + 2 >= xa && x4 + 2 <= xb) v.z = (v.z * 3.0f * gauss_e(x4 + 2, row, mx, my, c1, c2)) / den + v.z;
+      if (x4 + 3 >= xa && x4 + 3 <= xb) v.w = (v.w * 3.0f * gauss_e(x4 + 3, row, mx, my, c1, c2)) / den + v.w;
+    }
+    reinterpret_cast<float4*>(sm)[gi] = v;
+    vout[gi] = v;
+  }
+  float* src = sm;
+  int Hs = H2, Ws = W2;
+  for (int l = 1; l < p.L; l++) {
+    __syncthreads();
+    const int Hd = Hs >> 1, Wd = Ws >> 1;
+    float* dst = src + Hs * Ws;
+    float* gout = p.out[l] + pix * (size_t)(Hd * Wd);
+    for (int idx = threadIdx.x; idx < Hd * Wd; idx += VP_THREADS) {
+      const int y = idx / Wd, x = idx - y * Wd;
+      const float* s = src + (2 * y) * Ws + 2 * x;
+      const float o = (((s[0] + s[1]) + s[Ws]) + s[Ws + 1]) / 4.0f;
+      dst[idx] = o;
+      gout[idx] = o;
+    }
+    src = dst;
+    Hs = Hd;
+    Ws = Wd;
+  }
+}
+
 }  // namespace lgu
 
 extern "C" {
@@ -174,6 +243,35 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
   const unsigned grid = (unsigned)((npix + 3) / 4);
   hipLaunchKernelGGL(gaussmask_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), means,
                      covs, volume, volume1_grad, means_grad, covs_grad, npix, H2, W2, radius);
+  return launch_status();
+}
+
+int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int radius, void* stream) {
+  using namespace lgu;
+  if (!means || !covs || !volume || !levels || L < 1 || L > VP_MAXL) return LGU_E_BADARG;
+  if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
+  for (int l = 0; l < L; l++)
+    if (!levels[l]) return LGU_E_BADARG;
+  if (W2 % 4 != 0 || ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(levels[0])) & 15) != 0)
+    return LGU_E_UNSUPPORTED;
+  size_t floats = 0;
+  for (int l = 0, h = H2, w = W2; l < L; l++, h >>= 1, w >>= 1) floats += (size_t)h * w;
+  const size_t lds = floats * sizeof(float);
+  if (lds > 96 * 1024 || (H2 >> (L - 1)) < 1 || (W2 >> (L - 1)) < 1) return LGU_E_UNSUPPORTED;
+  if (E == 0) return LGU_OK;
+  VolPyrParams p;
+  p.means = means; p.covs = covs; p.vin = volume;
+  for (int l = 0; l < VP_MAXL; l++) p.out[l] = l < L ? levels[l] : nullptr;
+  p.npix = (size_t)E * H1 * W1; p.H2 = H2; p.W2 = W2; p.L = L; p.r = radius;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(volume_pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(volume_pyramid_kernel, dim3((unsigned)p.npix), dim3(VP_THREADS), lds,
+                     reinterpret_cast<hipStream_t>(stream), p);
   return launch_status();
 }
 

@@ -57,7 +57,9 @@ class GaussianMask(nn.Module):
         ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
         self.coord = torch.stack([xs, ys], dim=-1).view(h, w, 2)  # (x, y) of every source pixel
 
-    def forward(self, x, corr):
+    def gaussian_parameters(self, x):
+        """mean (b,h,w,2), cov (b,h,w,2) float32 contiguous, det (b,h*w) from the feature pair
+        x (b,h,w,256) — everything in forward() up to the kernel call (:66-83)."""
         b, h, w, _ = x.shape
         tt = self.mapA(x)
         mean_ofs = self.meanMap(tt).view(b, h, w, 2)
@@ -66,6 +68,11 @@ class GaussianMask(nn.Module):
         det = cov[:, :, 0] * cov[:, :, 1]
         cov = cov.view(b, h, w, 2).float()
         mean = self.coord.to(device=cov.device, dtype=cov.dtype).expand(b, h, w, 2) + mean_ofs
-        corr1 = GaussianMaskCuda.apply(mean.contiguous(), cov.contiguous(), corr, self.RADIUS)
+        return mean.contiguous(), cov.contiguous(), det
+
+    def forward(self, x, corr):
+        b, h, w, _ = x.shape
+        mean, cov, det = self.gaussian_parameters(x)
+        corr1 = GaussianMaskCuda.apply(mean, cov, corr, self.RADIUS)
         corr1 = corr1 / (6.28 * torch.sqrt(det).view(b, h, w, 1, 1)) + corr
         return corr1, mean, det

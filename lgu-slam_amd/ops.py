@@ -192,6 +192,24 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     return out
 
 
+def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False):
+    """Fused volume post-processing of CorrBlock.__init__ (reference gaussianMask_cuda.py:84-86
+    + corr.py:79-86): level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(det)) +
+    volume, levels 1.. by 2x2 average pooling of the target dims — one pass over the volume.
+    Returns the list of pyramid levels; with inplace=True level 0 reuses `volume`'s storage."""
+    _check(volume, "volume", means, "means", covs, "covs")
+    E, H1, W1, H2, W2 = volume.shape
+    levels = [volume if inplace else torch.empty_like(volume)]
+    for l in range(1, num_levels):
+        levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+    lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_volume_pyramid_f32(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2,
+                                                W2, radius, _stream(volume))
+    _lib.check(rc, "volume_pyramid")
+    return levels
+
+
 class DefcorrPyramidPlan:
     """Prepared launch of the fused pyramid sampler for a fixed pyramid / offset set: the
     pointer and size tables are built once, a call costs one ctypes invocation.  Used by

@@ -480,3 +480,37 @@ void oracle_defcorr_pyramid_fwd(const float* const* volumes, const float* coords
              sizeof(float) * rd * rd * HW1);
   }
 }
+
+/* ---------------------------------------------------------------------------------
+ * Volume post-processing of CorrBlock.__init__, restated op by op:
+ *   corr1 = gaussianMask(mean, cov, corr, r)                 (gaussianMask_cuda.py:84)
+ *   corr  = corr1 / (6.28*sqrt(cov0*cov1)) + corr            (gaussianMask_cuda.py:79,85-86)
+ *   level l = avg_pool2d(level l-1, 2, stride 2), l >= 1     (corr.py:83-86; ATen sums the
+ *             2x2 window row-major in fp32 and divides by 4)
+ * levels[l] (E,H1,W1,H2>>l,W2>>l); scratch holds one volume.
+ * --------------------------------------------------------------------------------- */
+void oracle_volume_pyramid(const float* means, const float* covs, const float* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int r, float* scratch) {
+  const size_t npix = (size_t)E * H1 * W1, HW2 = (size_t)H2 * W2;
+  oracle_gaussmask_fwd(means, covs, volume, scratch, E, H1, W1, H2, W2, r);
+#pragma omp parallel for schedule(static)
+  for (size_t p = 0; p < npix; p++) {
+    const float den = 6.28f * sqrtf(covs[p * 2 + 0] * covs[p * 2 + 1]);
+    for (size_t k = 0; k < HW2; k++) levels[0][p * HW2 + k] = scratch[p * HW2 + k] / den + volume[p * HW2 + k];
+  }
+  int Hs = H2, Ws = W2;
+  for (int l = 1; l < L; l++) {
+    const int Hd = Hs / 2, Wd = Ws / 2;
+    const float* src = levels[l - 1];
+    float* dst = levels[l];
+#pragma omp parallel for schedule(static)
+    for (size_t p = 0; p < npix; p++)
+      for (int y = 0; y < Hd; y++)
+        for (int x = 0; x < Wd; x++) {
+          const float* s = src + p * (size_t)Hs * Ws + (size_t)(2 * y) * Ws + 2 * x;
+          dst[p * (size_t)Hd * Wd + (size_t)y * Wd + x] = (((s[0] + s[1]) + s[Ws]) + s[Ws + 1]) / 4.0f;
+        }
+    Hs = Hd;
+    Ws = Wd;
+  }
+}

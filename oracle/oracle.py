@@ -164,3 +164,15 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False):
     lib().oracle_defcorr_pyramid_fwd(vp, _p(coords), op, _p(out), _i(L), _i(E), _i(H1), _i(W1), h2, w2,
                                      _i(radius), _i(1 if probe else 0), _p(sc), _p(so), _p(scr), _p(sp))
     return out
+
+
+def volume_pyramid(means, covs, volume, num_levels, radius=4):
+    """CorrBlock.__init__'s volume post-processing (gaussianMask_cuda.py:84-86 + corr.py:79-86).
+    Returns the list of num_levels pyramid levels (E,H1,W1,H2>>l,W2>>l)."""
+    E, H1, W1, H2, W2 = volume.shape
+    levels = [np.empty((E, H1, W1, H2 >> l, W2 >> l), np.float32) for l in range(num_levels)]
+    lp = (_f * num_levels)(*[_p(v) for v in levels])
+    scratch = np.empty_like(volume)
+    lib().oracle_volume_pyramid(_p(means), _p(covs), _p(volume), lp, _i(num_levels), _i(E), _i(H1), _i(W1), _i(H2),
+                                _i(W2), _i(radius), _p(scratch))
+    return levels

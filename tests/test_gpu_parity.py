@@ -282,6 +282,44 @@ def test_altcorr_forward_backward(lgu, oracle, cfg, variant):
         os.environ.pop("LGU_LOWMEM_VARIANT", None)
 
 
+@pytest.mark.parametrize("shape,L", [((2, 12, 16, 12, 16), 3), ((1, 48, 64, 48, 64), 4), ((2, 6, 8, 20, 24), 2)])
+def test_volume_pyramid_fused(lgu, oracle, shape, L):
+    """lgu_volume_pyramid_f32 == gaussianMask / (6.28 sqrt(det)) + corr, then avg-pool pyramid
+    (reference gaussianMask_cuda.py:84-86, corr.py:79-86): vs the oracle and vs the same
+    composition done with the separate op + torch on the GPU; in-place level 0."""
+    E, H1, W1, H2, W2 = shape
+    rng = np.random.default_rng(70 + H2)
+    v = rng.standard_normal(shape).astype(np.float32)
+    ys, xs = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
+    means = (np.stack([xs, ys], -1)[None].repeat(E, 0) * (W2 / W1) + rng.standard_normal((E, H1, W1, 2)) * 2).astype(np.float32)
+    covs = rng.uniform(0.05, 5.05, (E, H1, W1, 2)).astype(np.float32)
+    want = oracle.volume_pyramid(means, covs, v, L, 4)
+    got = lgu.ops.volume_pyramid(dev(means), dev(covs), dev(v), L, 4)
+    assert [tuple(t.shape) for t in got] == [w.shape for w in want]
+    for l in range(L):
+        assert np.abs(host(got[l]) - want[l]).max() <= 1e-5, l
+    # the composition of separate ops on the device
+    vd, md, cd = dev(v), dev(means), dev(covs)
+    c1, = lgu.ops.gaussianMask(md, cd, vd, 4)
+    lvl = c1 / (6.28 * torch.sqrt(cd[..., 0] * cd[..., 1]))[..., None, None] + vd
+    for l in range(L):
+        assert (got[l] - lvl).abs().max() <= 1e-6, l
+        lvl = torch.nn.functional.avg_pool2d(lvl.view(-1, 1, H2 >> l, W2 >> l), 2, stride=2).view(E, H1, W1, H2 >> (l + 1), W2 >> (l + 1))
+    # in place
+    vd2 = dev(v)
+    lev = lgu.ops.volume_pyramid(md, cd, vd2, L, 4, inplace=True)
+    assert lev[0].data_ptr() == vd2.data_ptr() and torch.equal(lev[0], got[0]) and torch.equal(lev[-1], got[-1])
+
+
+def test_torch_ops_namespace(lgu):
+    from lgu_slam_amd import torch_ops  # noqa: F401  (registers torch.ops.lgu.*)
+    case = inputs.pyramid_case(81, 1, 12, 16, 1, 3, 3.0, 4.0, True)
+    v, c, o = dev(case["volumes"][0]), dev(case["coords"]), dev(case["offsets"][0])
+    a = torch.ops.lgu.defCorr_index_forward(v, c, o.clone(), 3)
+    b = lgu.ops.defCorr_index_forward(v, c, o.clone(), 3)
+    assert isinstance(a, (list, tuple)) and torch.equal(a[0], b[0])
+
+
 def test_full_size_properties(lgu):
     """BASELINE cfg2 size (E=20, 48x64, L=4, r=3): size-independent properties instead of
     a full oracle run — linearity in the volume, zero-offset == plain sampler, variant
@@ -331,6 +369,12 @@ def test_corrblock_matches_reference_shaped_composition(lgu, oracle):
     with torch.no_grad():
         blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
         pyr = [host(v) for v in blk.corr_pyramid]
+        # fused __init__ (volume_pyramid) vs the reference-shaped composition GA.forward + avg_pool2d
+        vol = lgu.CorrBlock.corr(f1, f2).view(E, h, w, h, w).float()
+        ref0, _, _ = GA(blk.t, vol)
+        assert (blk.corr_pyramid[0] - ref0).abs().max() <= 1e-6
+        ref1 = torch.nn.functional.avg_pool2d(ref0.reshape(E * h * w, 1, h, w), 2, stride=2).view(E, h, w, h // 2, w // 2)
+        assert (blk.corr_pyramid[1] - ref1).abs().max() <= 1e-6
         offs = [host(o.contiguous()).reshape(E, h, w, 7, 7, 2).copy() for o in blk.offset]
         for it in range(2):
             coords1 = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device=dev_))

@@ -126,3 +126,11 @@ def test_edge_exchange_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res) and res[0][2] == [4, 3]
+
+
+def test_torch_library_registration(lgu):
+    from lgu_slam_amd import torch_ops
+    assert len(torch_ops.REGISTERED) == 9
+    sch = str(torch.ops.lgu.defCorr_index_forward.default._schema)
+    assert "Tensor(a2!) offset" in sch and sch.endswith("-> Tensor[]")  # in/out offset, list return
+    assert "Tensor fmap1" in str(torch.ops.lgu.altcorr_forward.default._schema)

@@ -118,3 +118,17 @@ def test_gaussian_mask_support_and_peak(oracle):
     assert out[0, 0, 0, 6, 7] == pytest.approx(3.0 * np.exp(-0.5), rel=1e-6)
     assert out[0, 0, 0, 1, 6] == 0 and out[0, 0, 0, 2, 6] > 0  # window = +-4 rows around floor(mean)
     assert out[0, 0, 0, 6, 11] == 0 and out[0, 0, 0, 6, 10] > 0
+
+
+def test_volume_pyramid_oracle_vs_torch_composition(oracle):
+    rng = np.random.default_rng(9)
+    E, H1, W1, H2, W2, L = 1, 4, 6, 12, 16, 3
+    v = rng.standard_normal((E, H1, W1, H2, W2)).astype(np.float32)
+    means = rng.uniform(2, 10, (E, H1, W1, 2)).astype(np.float32)
+    covs = rng.uniform(0.05, 5.05, (E, H1, W1, 2)).astype(np.float32)
+    got = oracle.volume_pyramid(means, covs, v, L, 4)
+    c1, = oracle.gaussianMask(means, covs, v, 4)
+    lvl = torch.from_numpy(c1) / (6.28 * torch.sqrt(torch.from_numpy(covs[..., 0] * covs[..., 1])))[..., None, None] + torch.from_numpy(v)
+    for l in range(L):
+        assert np.abs(got[l] - lvl.numpy()).max() <= 1e-6
+        lvl = F.avg_pool2d(lvl.view(-1, 1, H2 >> l, W2 >> l), 2, stride=2).view(E, H1, W1, H2 >> (l + 1), W2 >> (l + 1))

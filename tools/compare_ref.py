@@ -82,7 +82,22 @@ def main():
     print(json.dumps({"op": "gaussianMask E=8", "max_abs_diff_vs_reference": float((a - b).abs().max()),
                       "ref_ms": timeit(lambda: ref.gaussianMask(means, covs, vg, 4)),
                       "ours_ms": timeit(lambda: ops.gaussianMask(means, covs, vg, 4))}))
-    del vols, vg, a, b
+    # CorrBlock.__init__ volume post-processing: reference op + torch passes vs the fused kernel
+    def ref_post():
+        c1, = ref.gaussianMask(means, covs, vg, 4)
+        lvl = c1 / (6.28 * torch.sqrt(covs[..., 0] * covs[..., 1]))[..., None, None] + vg
+        outs = [lvl]
+        x = lvl.view(-1, 1, H1, W1)
+        for _ in range(3):
+            x = torch.nn.functional.avg_pool2d(x, 2, stride=2)
+            outs.append(x)
+        return outs
+    r_ = ref_post()
+    o_ = ops.volume_pyramid(means, covs, vg, 4, 4)
+    print(json.dumps({"op": "volume post-processing (mask + /den + corr + 3 pools) E=8",
+                      "max_abs_diff_vs_reference": max(float((a_.reshape(-1) - b_.reshape(-1)).abs().max()) for a_, b_ in zip(r_, o_)),
+                      "ref_ms": timeit(ref_post), "ours_ms": timeit(lambda: ops.volume_pyramid(means, covs, vg, 4, 4))}))
+    del vols, vg, a, b, r_, o_
     torch.cuda.empty_cache()
 
     # low-memory path, BASELINE config 4 shapes: 60x80 fmaps (needs H%4==0, W%8==0), C=128, B=16 edges
