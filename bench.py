@@ -133,6 +133,49 @@ def cpu_baseline(E, H1, W1, L, radius, budget_s=12.0):
     }
 
 
+def dry_run_cpu(args, rank, world):
+    """Same control flow as the real run (barrier, timed loop, max over ranks, exchange, one
+    JSON line on rank 0) on gloo/CPU with an empty step.  Used by tests/test_host.py only."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    E, H1, W1 = args.edges, 48, 64
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    barrier()
+    wall = max(time.perf_counter() - t0, 1e-9)
+    exchange = None
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        mine = torch.randn(E, H1, W1, 4)
+        allv = torch.empty(world * E, H1, W1, 4)
+        dist.all_gather_into_tensor(allv, mine)
+        exchange = {"op": "all_gather(target,weight) over gloo (dry run)", "bytes_per_rank": mine.numel() * 4, "ms": 0.0}
+    if rank == 0:
+        res = {"metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)", "value": world * E * H1 * W1 / (wall / args.steps) / 1e6,
+               "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "config": {"workload": "DRY RUN (no kernel executed)"},
+               "roofline": None, "cpu_baseline": None}
+        if exchange:
+            res["exchange"] = exchange
+        print(json.dumps(res, ensure_ascii=False))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +186,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="LGU_DEFCORR_VARIANT (A/B only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST ONLY: exercise the launch / process-group / timing / JSON logic with gloo on CPU and an "
+                         "empty step (no kernel runs, the printed value is meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +196,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)

@@ -311,6 +311,94 @@ def test_volume_pyramid_fused(lgu, oracle, shape, L):
     assert lev[0].data_ptr() == vd2.data_ptr() and torch.equal(lev[0], got[0]) and torch.equal(lev[-1], got[-1])
 
 
+def test_altcorrblock_matches_oracle_composition(lgu, oracle):
+    """Low-memory glue (reference corr.py:155-249): AltCorrBlock.__call__ == per level
+    [altcorr probe r=1 on level 1 -> var -> sigmoid -> offset[1] *= mask] + lowMem_defSample with
+    coords / 2^l, concatenated; every edge of the chunk samples with edge 0's offsets
+    (the reference's offset[b*n] indexing)."""
+    torch.manual_seed(5)
+    N, C, H, W = 4, 128, 24, 32
+    dev_ = "cuda"
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    fmaps = torch.randn(1, N, C, H, W, device=dev_) * 0.5
+    ii = torch.tensor([0, 0, 1, 2, 3], device=dev_)
+    jj = torch.tensor([1, 2, 3, 0, 2], device=dev_)
+    E = ii.numel()
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev_).float(), torch.arange(W, device=dev_).float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, H, W, 2, device=dev_)
+    with torch.no_grad():
+        blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        got = blk(coords, ii, jj)
+        assert got.shape == (1, E, 196, H, W)
+        # oracle composition from the same pyramid / offsets
+        f1 = host(blk.pyramid[0][0, ii].float().contiguous())
+        feats = torch.cat(((blk.pyramid[0][0, ii] * 4.0).permute(0, 3, 1, 2), (blk.pyramid[0][0, jj] * 4.0).permute(0, 3, 1, 2)), 1).float()
+        offs, _ = lgu.corr.generate_offsets(ofsMap, ofsRes, feats, 4)
+        offs = [host(o.contiguous()).reshape(E, H, W, 7, 7, 2).copy() for o in offs]
+        c = host(coords[0])  # (E,H,W,2)
+        outs = []
+        for l in range(4):
+            f2 = host(blk.pyramid[l][0, jj].float().contiguous())
+            cl = (c / 2 ** l).astype(np.float32).reshape(E, 1, H, W, 2)
+            if l == 1:
+                probe, = oracle.altcorr_forward(f1, f2, cl, 1)
+                pr = torch.from_numpy(probe).permute(0, 1, 3, 4, 2).contiguous().view(E, H, W, 3, 3)
+                mask = torch.sigmoid(torch.var(pr, dim=[3, 4])).numpy().reshape(E, H, W, 1, 1, 1)
+                offs[1] = (offs[1] * mask).astype(np.float32)
+            corr, = oracle.lowMem_defSample(f1, f2, cl, offs[l], 3)
+            outs.append(corr.reshape(E, 49, H, W))
+        want = np.concatenate(outs, 1)
+    assert np.abs(host(got)[0] - want).max() <= 2e-5
+
+
+def test_autograd_functions_route_gradients(lgu, oracle):
+    """a10: CorrSampler / DefCorrSampler / GaussianMaskCuda (reference corr.py:10-42,
+    gaussianMask_cuda.py:7-23): grads for volume and offset (never coords), mean and cov (never corr)."""
+    rng = np.random.default_rng(90)
+    E, H1, W1 = 1, 8, 16
+    v = rng.standard_normal((E, H1, W1, H1, W1)).astype(np.float32)
+    c = inputs.grid_coords(rng, E, H1, W1, 2.0)
+    off = (3 * np.tanh(rng.standard_normal((E, H1, W1, 7, 7, 2)))).astype(np.float32)
+    g = rng.standard_normal((E, 7, 7, H1, W1)).astype(np.float32)
+    vd = dev(v).requires_grad_(True)
+    od = dev(off).requires_grad_(True)
+    cd = dev(c).requires_grad_(True)
+    out = lgu.DefCorrSampler.apply(vd, cd, od, 3)
+    out.backward(dev(g))
+    vg_w, og_w = oracle.defCorr_index_backward(v, c, off.copy(), g, 3)
+    assert cd.grad is None
+    assert np.abs(host(vd.grad) - vg_w).max() <= 1e-5 * max(1.0, np.abs(vg_w).max())
+    assert np.abs(host(od.grad) - og_w).max() <= 1e-5 * max(1.0, np.abs(og_w).max())
+    vd2 = dev(v).requires_grad_(True)
+    out2 = lgu.CorrSampler.apply(vd2, dev(c), 3)
+    out2.backward(dev(g))
+    pvg_w, = oracle.corr_index_backward(v, c, g, 3)
+    assert np.abs(host(vd2.grad) - pvg_w).max() <= 1e-5 * max(1.0, np.abs(pvg_w).max())
+    ys, xs = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
+    means = (np.stack([xs, ys], -1)[None] + rng.standard_normal((E, H1, W1, 2))).astype(np.float32)
+    covs = rng.uniform(0.5, 4.0, (E, H1, W1, 2)).astype(np.float32)
+    md, kd, vd3 = dev(means).requires_grad_(True), dev(covs).requires_grad_(True), dev(v).requires_grad_(True)
+    gv = rng.standard_normal(v.shape).astype(np.float32)
+    lgu.GaussianMaskCuda.apply(md, kd, vd3, 4).backward(dev(gv))
+    mg_w, cg_w = oracle.gaussianMask_backward(means, covs, v, gv, 4)
+    assert vd3.grad is None
+    assert np.abs(host(md.grad) - mg_w).max() <= 1e-5 * max(1.0, np.abs(mg_w).max())
+    assert np.abs(host(kd.grad) - cg_w).max() <= 1e-5 * max(1.0, np.abs(cg_w).max())
+
+
+def test_empty_edge_list(lgu):
+    """E = 0 (a factor graph with no edges yet): every op returns correctly shaped empty tensors."""
+    z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    assert lgu.ops.corr_index_forward(z(0, 8, 16, 8, 16), z(0, 2, 8, 16), 1)[0].shape == (0, 3, 3, 8, 16)
+    assert lgu.ops.defCorr_index_forward(z(0, 8, 16, 8, 16), z(0, 2, 8, 16), z(0, 8, 16, 7, 7, 2), 3)[0].shape == (0, 7, 7, 8, 16)
+    out = lgu.ops.defcorr_pyramid_forward([z(0, 8, 16, 8, 16), z(0, 8, 16, 4, 8)], z(0, 2, 8, 16), [z(0, 8, 16, 7, 7, 2)] * 2, 3)
+    assert out.shape == (0, 98, 8, 16)
+    assert lgu.ops.gaussianMask(z(0, 8, 16, 2), z(0, 8, 16, 2), z(0, 8, 16, 8, 16), 4)[0].numel() == 0
+    assert lgu.ops.lowMem_defSample(z(0, 8, 16, 32), z(0, 8, 16, 32), z(0, 1, 8, 16, 2), z(1, 8, 16, 7, 7, 2), 3)[0].shape == (0, 1, 7, 7, 8, 16)
+    assert lgu.ops.altcorr_forward(z(0, 8, 16, 32), z(0, 8, 16, 32), z(0, 1, 8, 16, 2), 1)[0].shape == (0, 1, 9, 8, 16)
+
+
 def test_torch_ops_namespace(lgu):
     from lgu_slam_amd import torch_ops  # noqa: F401  (registers torch.ops.lgu.*)
     case = inputs.pyramid_case(81, 1, 12, 16, 1, 3, 3.0, 4.0, True)

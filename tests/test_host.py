@@ -134,3 +134,22 @@ def test_torch_library_registration(lgu):
     sch = str(torch.ops.lgu.defCorr_index_forward.default._schema)
     assert "Tensor(a2!) offset" in sch and sch.endswith("-> Tensor[]")  # in/out offset, list return
     assert "Tensor fmap1" in str(torch.ops.lgu.altcorr_forward.default._schema)
+
+
+def test_bench_distributed_control_flow_gloo_world2():
+    """bench.py's multi-rank launch contract (torch.distributed.run, RANK/WORLD_SIZE env, barrier +
+    max-over-ranks timing, exchange, ONE JSON line from rank 0) exercised on CPU with gloo."""
+    import json
+    import subprocess
+    port = 29600 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--dry-run-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["exchange"]["bytes_per_rank"] == 20 * 48 * 64 * 4 * 4
+    for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert k in d
