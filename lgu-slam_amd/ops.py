@@ -47,6 +47,8 @@ def defCorr_index_forward(volume, coords, offset, radius):
     if tuple(coords.shape) != (E, 2, H1, W1) or offset.numel() != E * H1 * W1 * rd * rd * 2:
         raise RuntimeError("defCorr_index_forward: shape mismatch between volume, coords and offset")
     corr = torch.empty((E, rd, rd, H1, W1), dtype=volume.dtype, device=volume.device)
+    if E == 0:
+        return [corr]  # no edges: nothing to launch (empty tensors have null data pointers)
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_defcorr_fwd_f32(_ptr(volume), _ptr(coords), _ptr(offset), _ptr(corr),
                                              E, H1, W1, H2, W2, radius, _stream(volume))
@@ -59,6 +61,8 @@ def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
     offset_grad = torch.empty_like(offset)
+    if E == 0:
+        return [volume_grad, offset_grad]
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_defcorr_bwd_f32(_ptr(volume), _ptr(coords), _ptr(offset), _ptr(corr_grad),
                                              _ptr(volume_grad), _ptr(offset_grad), E, H1, W1, H2, W2, radius,
@@ -74,6 +78,8 @@ def corr_index_forward(volume, coords, radius):
     if tuple(coords.shape) != (E, 2, H1, W1):
         raise RuntimeError("corr_index_forward: coords must be (E,2,H1,W1)")
     corr = torch.empty((E, rd, rd, H1, W1), dtype=volume.dtype, device=volume.device)
+    if E == 0:
+        return [corr]
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_corridx_fwd_f32(_ptr(volume), _ptr(coords), _ptr(corr), E, H1, W1, H2, W2, radius,
                                              _stream(volume))
@@ -85,6 +91,8 @@ def corr_index_backward(volume, coords, corr_grad, radius):
     _check(volume, "volume", coords, "coords", corr_grad, "corr_grad")
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
+    if E == 0:
+        return [volume_grad]
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_corridx_bwd_f32(_ptr(volume), _ptr(coords), _ptr(corr_grad), _ptr(volume_grad),
                                              E, H1, W1, H2, W2, radius, _stream(volume))
@@ -96,6 +104,8 @@ def gaussianMask(means, covs, volume, radius):
     _check(volume, "volume", means, "means", covs, "covs")
     E, H1, W1, H2, W2 = volume.shape
     volume1 = torch.empty_like(volume)
+    if E == 0:
+        return [volume1]
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_gaussmask_fwd_f32(_ptr(means), _ptr(covs), _ptr(volume), _ptr(volume1),
                                                E, H1, W1, H2, W2, radius, _stream(volume))
@@ -108,6 +118,8 @@ def gaussianMask_backward(means, covs, volume, volume_grad, radius):
     E, H1, W1, H2, W2 = volume.shape
     means_grad = torch.empty_like(means)
     covs_grad = torch.empty_like(covs)
+    if E == 0:
+        return [means_grad, covs_grad]
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_gaussmask_bwd_f32(_ptr(means), _ptr(covs), _ptr(volume), _ptr(volume_grad),
                                                _ptr(means_grad), _ptr(covs_grad), E, H1, W1, H2, W2, radius,
@@ -122,6 +134,8 @@ def lowMem_defSample(fmap1, fmap2, coords, offset, radius):
     _, H2, W2, C = fmap2.shape
     rd = 2 * radius + 1
     corr = torch.empty((B, S, rd, rd, H1, W1), dtype=fmap1.dtype, device=fmap1.device)
+    if B == 0:
+        return [corr]
     with torch.cuda.device(fmap1.device):
         rc = _lib.load().lgu_lowmem_defsample_fwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(offset), _ptr(corr),
                                                       B, S, H1, W1, H2, W2, C, offset.shape[0], radius,
@@ -136,6 +150,8 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
     _, H2, W2, C = fmap2.shape
     rd = 2 * radius + 1
     corr = torch.empty((B, S, rd * rd, H1, W1), dtype=fmap1.dtype, device=fmap1.device)
+    if B == 0:
+        return [corr]
     with torch.cuda.device(fmap1.device):
         rc = _lib.load().lgu_altcorr_fwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr),
                                              B, S, H1, W1, H2, W2, C, radius, _stream(fmap1))
@@ -150,6 +166,8 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     fmap1_grad = torch.empty_like(fmap1)
     fmap2_grad = torch.zeros_like(fmap2)
     coords_grad = torch.zeros_like(coords)  # allocated, never written by the reference (altcorr_kernel.cu:336)
+    if B == 0:
+        return [fmap1_grad, fmap2_grad, coords_grad]
     with torch.cuda.device(fmap1.device):
         rc = _lib.load().lgu_altcorr_bwd_f32(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr_grad),
                                              _ptr(fmap1_grad), _ptr(fmap2_grad), B, S, H1, W1, H2, W2, C, radius,
@@ -181,6 +199,8 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
         out = torch.empty((E, L * rd * rd, H1, W1), dtype=torch.float32, device=coords.device)
     else:
         _check(out, "out")
+    if E == 0:
+        return out
     vp = (_vp * L)(*[v.data_ptr() for v in volumes])
     op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
     h2 = (ctypes.c_int * L)(*[v.shape[3] for v in volumes])
@@ -202,6 +222,8 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False):
     levels = [volume if inplace else torch.empty_like(volume)]
     for l in range(1, num_levels):
         levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+    if E == 0:
+        return levels
     lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
     with torch.cuda.device(volume.device):
         rc = _lib.load().lgu_volume_pyramid_f32(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2,
@@ -244,6 +266,8 @@ class DefcorrPyramidPlan:
         _check(coords, "coords")
         if out is None:
             out = torch.empty((self.E, self.channels, self.H1, self.W1), dtype=torch.float32, device=self.device)
+        if self.E == 0:
+            return out
         rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
                       self._h2, self._w2, self.radius, self.flags,
                       torch.cuda.current_stream(self.device).cuda_stream)
