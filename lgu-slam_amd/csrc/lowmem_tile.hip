@@ -25,21 +25,22 @@
 // take a per-tap fallback (lanes = taps, sequential channels) — correct for any offsets.
 // Channel sums run sequentially with FMA per position; the reference sums 32-channel chunks
 // of pre-blended values: equal to fp32 rounding (tests: 1e-5).
+#include <type_traits>
+
 #include "lgu_common.hpp"
 
 namespace lgu {
 
 constexpr int LT_W = 16, LT_H = 4, LT_PIX = LT_W * LT_H;
 constexpr int LT_WAVES = 16, LT_PPW = LT_PIX / LT_WAVES;  // 1024 threads, 4 pixels per wave, one workgroup per CU
-constexpr int LT_CH = 16;                                 // channels per staged chunk
-constexpr int LT_Q4 = LT_CH / 4;                          // float4 per staged position
-constexpr int LT_PITCH = LT_CH + 4;                       // floats per staged position (80 B: conflict-free b128 reads)
-constexpr int LT_MAXPOS = 1440;                           // staged positions (115 200 B)
-constexpr int LT_MAXBOX = 4 * kWave;                      // patch entries per pixel
+constexpr int LT_CH = 16;                                 // channels per staged chunk (8 for windows that only fit at the smaller pitch)
+constexpr int LT_STAGE_FLOATS = 1536 * (LT_CH + 4);       // stage: 1536 positions at the 80-byte pitch = 2560 at the 48-byte pitch (122 880 B)
+constexpr int LT_MAXPOS = LT_STAGE_FLOATS / (8 + 4);      // largest padded window served (2560 positions)
+constexpr int LT_BOXW = 16;                               // patch row pitch: boxes up to 16 x 16 positions
+constexpr int LT_MAXBOX = LT_BOXW * LT_BOXW;              // patch entries per pixel (4 per lane)
 constexpr int LT_OUTP = LT_PIX + 1;
 constexpr int LT_SCMAX = 4;                               // chunks staged per barrier pair when the window is small
 
-__device__ __forceinline__ size_t lt_smem_floats() { return (size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8; }
 
 template <int R>
 __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const float* __restrict__ fmap1,
@@ -50,12 +51,12 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
                                                                        int tiles_y) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   extern __shared__ float4 smem4[];
-  float* const stage = reinterpret_cast<float*>(smem4);       // [LT_MAXPOS][LT_PITCH]
-  float* const dscr = stage + LT_MAXPOS * LT_PITCH;           // [LT_WAVES][LT_MAXBOX]
-  int* const pbox = reinterpret_cast<int*>(dscr + LT_WAVES * LT_MAXBOX);  // [LT_PIX][4] xlo,ylo,bw,bh
+  float* const stage = reinterpret_cast<float*>(smem4);       // [positions][pitch], LT_STAGE_FLOATS
+  float* const dscr = stage + 4096;                           // [LT_WAVES][LT_MAXBOX] patch scratch, aliases the stage too
+  int* const pbox = reinterpret_cast<int*>(stage + LT_STAGE_FLOATS);  // [LT_PIX][4] xlo,ylo,bw,bh
   int* const ubox = pbox + LT_PIX * 4;                        // xmin,ymin,xmax,ymax of the tile window
   float* const f1s = reinterpret_cast<float*>(ubox + 8);      // [LT_PIX][SC*LT_CH] fmap1 chunk(s) of the tile's pixels
-  float* const outt = stage;                                  // [NT][LT_OUTP], aliases the stage after the chunk loop
+  float* const outt = stage;                                  // [NT][LT_OUTP] (< 4096 floats), aliases the stage after the chunk loop
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
       pbox[pw * 4 + 0] = xlo; pbox[pw * 4 + 1] = ylo;
       pbox[pw * 4 + 2] = any ? xhi - xlo + 1 : 0;
       pbox[pw * 4 + 3] = any ? yhi - ylo + 1 : 0;
-      if (any && (xhi - xlo + 1) * (yhi - ylo + 1) <= LT_MAXBOX) {  // oversize boxes use the fallback, keep them out of the window
+      if (any && xhi - xlo < LT_BOXW && yhi - ylo < LT_BOXW) {  // oversize boxes use the fallback, keep them out of the window
         atomicMin(&ubox[0], xlo); atomicMin(&ubox[1], ylo);
         atomicMax(&ubox[2], xhi); atomicMax(&ubox[3], yhi);
       }
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   const int UX0 = ubox[0], UY0 = ubox[1];
   const int UW = ubox[2] - UX0 + 1, UH = ubox[3] - UY0 + 1;
   const bool have_window = ubox[2] >= 0;
-  const int npos = have_window ? UW * UH : 0;
+  // window rows are padded to a multiple of 16 positions: with the 80-byte position pitch and the
+  // fixed 16-wide patch rows below, every ds_read_b128 lane group then covers all 64 banks once
+  const int UWp = (UW + 15) & ~15;
+  const int npos = have_window ? UWp * UH : 0;
   const bool tiled = have_window && npos <= LT_MAXPOS;  // workgroup-uniform
 
   float acc[LT_PPW][4];
@@ -143,62 +147,66 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   for (int k = 0; k < LT_PPW; k++) {
     const int pw = w * LT_PPW + k;
     const int xlo = pbox[pw * 4 + 0], ylo = pbox[pw * 4 + 1], bw = pbox[pw * 4 + 2], bh = pbox[pw * 4 + 3];
-    const int nb = bw * bh;
-    const float rbw = 1.0f / (float)(bw > 0 ? bw : 1);
+    const bool boxed = tiled && bw > 0 && bw <= LT_BOXW && bh <= LT_BOXW;
     lpos[k][0] = lpos[k][1] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       acc[k][j] = 0.0f;
-      const int q = lane + j * kWave;
-      const int qy = (int)(((float)q + 0.5f) * rbw);
-      const int qx = q - qy * bw;
-      const unsigned ps = (tiled && nb <= LT_MAXBOX && q < nb) ? (unsigned)((ylo + qy - UY0) * UW + (xlo + qx - UX0)) : 0xffffu;
+      const int q = lane + j * kWave;            // patch entry (qy, qx) = (q / 16, q % 16)
+      const int qy = q >> 4, qx = q & (LT_BOXW - 1);
+      const unsigned ps = (boxed && qx < bw && qy < bh) ? (unsigned)((ylo + qy - UY0) * UWp + (xlo + qx - UX0)) : 0xffffu;
       lpos[k][j >> 1] |= ps << (16 * (j & 1));
     }
   }
 
   // ---- phase 1: stage the window chunk by chunk, accumulate every pixel's patch ----
-  if (tiled) {
-    const float rUW = 1.0f / (float)UW;
+  // The channel chunk is 16 floats (80-byte position pitch) when the padded window fits the stage
+  // at that pitch and 8 floats (48-byte pitch, conflict-free by the same argument) for larger
+  // windows: the stage holds LT_STAGE_FLOATS either way.
+  auto chunk_loop = [&](auto ch_tag) __attribute__((always_inline)) {
+    constexpr int CH = decltype(ch_tag)::value;
+    constexpr int Q4 = CH / 4, PITCH = CH + 4;
+    constexpr int CAP = LT_STAGE_FLOATS / PITCH;  // positions the stage holds at this pitch
+    const float rUW = 1.0f / (float)UWp;
     // small windows (coarse pyramid levels): stage SC chunks per barrier pair
     int SC = 1;
-    if (npos * 4 <= LT_MAXPOS && C % (LT_CH * 4) == 0) SC = 4;
-    else if (npos * 2 <= LT_MAXPOS && C % (LT_CH * 2) == 0) SC = 2;
+    if (npos * 4 <= CAP && C % (CH * 4) == 0 && CH * 4 <= LT_CH * LT_SCMAX) SC = 4;
+    else if (npos * 2 <= CAP && C % (CH * 2) == 0) SC = 2;
     const int nvp = npos * SC;  // virtual positions: (sub-chunk, position)
     const float rnpos = 1.0f / (float)npos;
     // each thread's share of the window (chunk-invariant): source offsets relative to F2 + c0.
     // The NEXT chunk's global loads are issued before the current chunk's FMAs (register
     // prefetch), so only the LDS write sits between the two barriers.
-    constexpr int NPRE = (LT_MAXPOS * LT_Q4 + LT_WAVES * kWave - 1) / (LT_WAVES * kWave);
+    constexpr int NPRE = (CAP * Q4 + LT_WAVES * kWave - 1) / (LT_WAVES * kWave);
     int soff[NPRE];
     float4 pre[NPRE], pf1 = make_float4(0.f, 0.f, 0.f, 0.f);
     int f1off = -1;
-    if (tid < LT_PIX * LT_Q4 * SC) {  // fmap1 chunk(s) of the tile's 64 pixels (read back as LDS broadcasts)
-      const int pw = tid / (LT_Q4 * SC);
+    if (tid < LT_PIX * Q4 * SC) {  // fmap1 chunk(s) of the tile's 64 pixels (read back as LDS broadcasts)
+      const int pw = tid / (Q4 * SC);
       const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
-      if (h1 < H1 && w1 < W1) f1off = (h1 * W1 + w1) * C + (tid - pw * LT_Q4 * SC) * 4;
+      if (h1 < H1 && w1 < W1) f1off = (h1 * W1 + w1) * C + (tid - pw * Q4 * SC) * 4;
     }
     if (f1off >= 0) pf1 = *reinterpret_cast<const float4*>(F1 + f1off);
 #pragma unroll
     for (int i = 0; i < NPRE; i++) {
       const int idx = tid + i * LT_WAVES * kWave;
-      const int vp = idx / LT_Q4;
+      const int vp = idx / Q4;
       const int sc = (int)(((float)vp + 0.5f) * rnpos);
       const int pos = vp - sc * npos;
       const int uy = (int)(((float)pos + 0.5f) * rUW);
-      const int ux = pos - uy * UW;
-      soff[i] = idx < nvp * LT_Q4 ? ((UY0 + uy) * W2 + (UX0 + ux)) * C + sc * LT_CH + (idx % LT_Q4) * 4 : -1;
+      const int ux = pos - uy * UWp;
+      soff[i] = (idx < nvp * Q4 && ux < UW) ? ((UY0 + uy) * W2 + (UX0 + ux)) * C + sc * CH + (idx % Q4) * 4 : -1;
       pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (soff[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(F2 + soff[i]);  // chunk 0
     }
-    const int cstep = LT_CH * SC;
+    const int cstep = CH * SC;
     for (int c0 = 0; c0 < C; c0 += cstep) {
       __syncthreads();  // previous chunk fully consumed
-      if (tid < LT_PIX * LT_Q4 * SC) *reinterpret_cast<float4*>(f1s + tid * 4) = pf1;
+      if (tid < LT_PIX * Q4 * SC) *reinterpret_cast<float4*>(f1s + tid * 4) = pf1;
 #pragma unroll
       for (int i = 0; i < NPRE; i++) {
         const int idx = tid + i * LT_WAVES * kWave;
-        if (soff[i] >= 0) *reinterpret_cast<float4*>(stage + (idx / LT_Q4) * LT_PITCH + (idx % LT_Q4) * 4) = pre[i];
+        if (soff[i] >= 0) *reinterpret_cast<float4*>(stage + (idx / Q4) * PITCH + (idx % Q4) * 4) = pre[i];
       }
       __syncthreads();
       if (c0 + cstep < C) {
@@ -208,23 +216,23 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
           if (soff[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(F2 + soff[i] + c0 + cstep);
       }
       for (int sc = 0; sc < SC; sc++) {
-        const float* stg = stage + sc * npos * LT_PITCH;
+        const float* stg = stage + sc * npos * PITCH;
 #pragma unroll
         for (int k = 0; k < LT_PPW; k++) {
           const int pw = w * LT_PPW + k;
           const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
           if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
-          float4 f1[LT_Q4];  // same address in every lane: LDS broadcast
+          float4 f1[Q4];  // same address in every lane: LDS broadcast
 #pragma unroll
-          for (int i = 0; i < LT_Q4; i++) f1[i] = *reinterpret_cast<const float4*>(f1s + (pw * SC + sc) * LT_CH + i * 4);
+          for (int i = 0; i < Q4; i++) f1[i] = *reinterpret_cast<const float4*>(f1s + (pw * SC + sc) * CH + i * 4);
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const unsigned ps = (lpos[k][j >> 1] >> (16 * (j & 1))) & 0xffffu;
             if (ps != 0xffffu) {
               float s = acc[k][j];
 #pragma unroll
-              for (int i = 0; i < LT_Q4; i++) {
-                const float4 a = *reinterpret_cast<const float4*>(stg + ps * LT_PITCH + i * 4);
+              for (int i = 0; i < Q4; i++) {
+                const float4 a = *reinterpret_cast<const float4*>(stg + ps * PITCH + i * 4);
                 s = __builtin_fmaf(f1[i].x, a.x, s); s = __builtin_fmaf(f1[i].y, a.y, s);
                 s = __builtin_fmaf(f1[i].z, a.z, s); s = __builtin_fmaf(f1[i].w, a.w, s);
               }
@@ -235,6 +243,10 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
       }
     }
     __syncthreads();  // the stage is dead from here on: it becomes the output tile
+  };
+  if (tiled) {
+    if (npos <= LT_STAGE_FLOATS / (16 + 4) && C % 16 == 0) chunk_loop(std::integral_constant<int, 16>{});
+    else chunk_loop(std::integral_constant<int, 8>{});
   }
 
   // ---- phase 2: sample every pixel's patch (or fall back to per-tap dots) ----
@@ -262,18 +274,17 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
     const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
     const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
     float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-    if (tiled && bw * bh <= LT_MAXBOX) {
+    if (tiled && bw <= LT_BOXW && bh <= LT_BOXW) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (lane + j * kWave < bw * bh) D[lane + j * kWave] = acc[k][j];
+      for (int j = 0; j < 4; j++) D[lane + j * kWave] = acc[k][j];  // [qy][16]
       __builtin_amdgcn_wave_barrier();
       if (tap) {
-        const int o = (h2 - ylo) * bw + (w2 - xlo);
+        const int o = (h2 - ylo) * LT_BOXW + (w2 - xlo);
         if (b11) q11 = D[o];
         if (b21) q21 = D[o + 1];
-        if (b12) q12 = D[o + bw];
-        if (b22) q22 = D[o + bw + 1];
+        if (b12) q12 = D[o + LT_BOXW];
+        if (b22) q22 = D[o + LT_BOXW + 1];
       }
     } else if (tap) {
       // fallback: this lane's four corner dots, channels in order
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
 template <int R>
 static int launch_tile(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
                        int S, int H1, int W1, int H2, int W2, int C, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)LT_MAXPOS * LT_PITCH + LT_WAVES * LT_MAXBOX + LT_PIX * 4 + 8 + LT_PIX * LT_CH * LT_SCMAX);
+  const size_t lds = sizeof(float) * ((size_t)LT_STAGE_FLOATS + LT_PIX * 4 + 8 + LT_PIX * LT_CH * LT_SCMAX);
   auto kern = lowmem_tile_kernel<R>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -327,7 +338,7 @@ static int launch_tile(const float* fmap1, const float* fmap2, const float* coor
 int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
                          int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
   const bool aligned = ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
-  if (radius < 1 || radius > 3 || C % LT_CH != 0 || !aligned || S > 65535) return -1;
+  if (radius < 1 || radius > 3 || C % 8 != 0 || !aligned || S > 65535) return -1;
   switch (radius) {
     case 1: return launch_tile<1>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
     case 2: return launch_tile<2>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
