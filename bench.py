@@ -273,7 +273,8 @@ def main():
 
     if rank == 0:
         A, U = algorithmic_bytes_per_unit(vols, coords, offs, R)
-        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2>", 3: "lgu::defcorr_gather_kernel<3,%s,12,4>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
+        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,32>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32>", 5: "lgu::defcorr_gather_kernel<3,%s,12,2,16>",
+                 3: "lgu::defcorr_gather_kernel<3,%s,12,4,16>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
                  2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline

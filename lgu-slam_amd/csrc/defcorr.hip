@@ -391,15 +391,15 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // CU's L1 for the other three corners.  Every load of the wave's 16 jobs is issued before
 // the first result is used.  Far fewer instructions per pixel than the LDS-DMA kernel; the
 // price is L1/TA work per corner instead of per line.
-// GP = pixels per wave (TP / GP waves per workgroup)
-template <int R, bool PROBE, int ZMASK, int GP>
-__global__ __launch_bounds__((TP / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
+// GP = pixels per wave, TPX = pixels (along x) per workgroup: TPX / GP waves per workgroup
+template <int R, bool PROBE, int ZMASK, int GP, int TPX>
+__global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   constexpr int LAT = 2 * R + 2;
   constexpr int LATP = LAT <= 4 ? 4 : 8;
   constexpr int PIXOP = kWave / (LATP * LATP);
   extern __shared__ float4 lds4[];
-  float* const outst = reinterpret_cast<float*>(lds4);  // [L*NT][OUT_PITCH]
+  float* const outst = reinterpret_cast<float*>(lds4);  // [L*NT][(TPX + 1)]
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__((TP / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) v
   bid /= p.tiles_per_row;
   const int y = bid % p.H1;
   const int e = bid / p.H1;
-  const int xbase = tile * TP;
+  const int xbase = tile * TPX;
 
   const bool tap = lane < NT;
   const int ti = lane / RD, tj = lane - ti * RD;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__((TP / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) v
         float val = 0.0f;
         if (in_bounds(y1, x1, H2, W2)) val = bilerp(q11, q21, q12, q22, dx, dy);
         if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < GP))
-          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * OUT_PITCH + (w * GP + (PIXOP == 1 ? k : lpix))] = val;
+          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * (TPX + 1) + (w * GP + (PIXOP == 1 ? k : lpix))] = val;
         continue;
       }
       if (!pv) continue;
@@ -598,16 +598,16 @@ __global__ __launch_bounds__((TP / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) v
       const float q12 = (fl & 4) ? q[k][l][2] : 0.0f;
       const float q22 = ((fl & 6) == 6) ? q[k][l][3] : 0.0f;
       const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
-      if (tap) outst[(l * NT + lane) * OUT_PITCH + (w * GP + k)] = val;
+      if (tap) outst[(l * NT + lane) * (TPX + 1) + (w * GP + k)] = val;
     }
   }
   __syncthreads();
 
-  const int nout = p.L * NT * TP;
+  const int nout = p.L * NT * TPX;
   float* const orow = p.out + (((size_t)e * p.Ctot + p.cbase) * p.H1 + y) * p.W1 + xbase;
-  for (int idx = threadIdx.x; idx < nout; idx += (TP / GP) * kWave) {
-    const int c = idx >> 4, pc = idx & (TP - 1);
-    if (xbase + pc < p.W1) orow[(size_t)c * HW1 + pc] = outst[c * OUT_PITCH + pc];
+  for (int idx = threadIdx.x; idx < nout; idx += (TPX / GP) * kWave) {
+    const int c = idx / TPX, pc = idx & (TPX - 1);
+    if (xbase + pc < p.W1) orow[(size_t)c * HW1 + pc] = outst[c * (TPX + 1) + pc];
   }
 }
 
@@ -671,17 +671,21 @@ static size_t pyr_lds_bytes(int L, int radius) {
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
-  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * OUT_PITCH;
+  constexpr int tpx = KIND == 3 ? 32 : TP;
+  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
   auto kern = KIND == 0 ? defcorr_pyr_kernel<R, PROBE, ZMASK>
-                        : KIND == 1 ? defcorr_gather_kernel<R, PROBE, ZMASK, 4> : defcorr_gather_kernel<R, PROBE, ZMASK, 2>;
-  const int nthreads = KIND == 2 ? (TP / 2) * kWave : NWAVE * kWave;
+              : KIND == 1 ? defcorr_gather_kernel<R, PROBE, ZMASK, 4, 16>
+              : KIND == 2 ? defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16> : defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32>;
+  const int nthreads = KIND == 3 ? 16 * kWave : KIND == 2 ? 8 * kWave : NWAVE * kWave;
+  PyrParams q = p;
+  q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
   static bool attr_set = false;  // idempotent; racing setters write the same value
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((size_t)p.E * p.H1 * p.tiles_per_row);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, p);
+  const unsigned grid = (unsigned)((size_t)q.E * q.H1 * q.tiles_per_row);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, q);
   return launch_status();
 }
 
@@ -702,8 +706,9 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = register-gather kernel, 2 px/wave, 512-thread workgroups
-  // (production), 3 = the same with 4 px/wave, 1 = LDS-DMA staged kernel, 2 = generic
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production (register-gather kernel, 2 px/wave, 32- or
+  // 16-pixel tiles by W1), 4 / 5 = force 32- / 16-pixel tiles, 3 = 4 px/wave with 16-pixel tiles,
+  // 1 = LDS-DMA staged kernel, 2 = generic
   // one-thread-per-output kernel (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
 
@@ -750,7 +755,13 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
 #define LGU_LAUNCH_K(PR, ZM, KD)                                                                   \
   (radius == 3 ? launch_fast<3, PR, ZM, KD>(p, st)                                                 \
                : radius == 2 ? launch_fast<2, PR, ZM, KD>(p, st) : launch_fast<1, PR, ZM, KD>(p, st))
-#define LGU_LAUNCH(PR, ZM) (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0) : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : LGU_LAUNCH_K(PR, ZM, 2))
+      // production choice of tile width: 32 pixels (full 128-byte output lines, 1024-thread
+      // workgroups) unless 16-pixel tiles waste fewer lanes on this W1
+      const int slots16 = ((W1 + 15) / 16) * 16, slots32 = ((W1 + 31) / 32) * 32;
+      const bool wide = variant == 4 || (variant != 5 && slots32 <= slots16);
+#define LGU_LAUNCH(PR, ZM)                                         \
+  (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                          \
+                : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
       else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
 #undef LGU_LAUNCH

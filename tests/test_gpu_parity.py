@@ -74,7 +74,7 @@ PYR_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("name", list(PYR_CASES))
 def test_defcorr_pyramid_matches_oracle(lgu, oracle, name, variant):
     seed, E, H1, W1, L, radius, sigma, osc, dense = PYR_CASES[name]
@@ -100,7 +100,7 @@ PROBE_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 5])
 @pytest.mark.parametrize("name", list(PROBE_CASES))
 def test_fused_probe_matches_oracle(lgu, oracle, name, variant):
     """LGU_PYR_PROBE: in-kernel 3x3 probe of level 1 -> var -> sigmoid -> offset[1] *= mask
