@@ -202,7 +202,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
     if args.variant:
@@ -227,7 +228,7 @@ def main():
         plan(coords, out=out)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -244,7 +245,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,7 +254,7 @@ def main():
     value = world * units / (wall / args.steps) / 1e6
 
     exchange = None
-    if world > 1:  # the sharded driver's per-BA-step all-gather of target+weight (E,ht,wd,2)x2
+    if use_dist:  # the sharded driver's per-BA-step all-gather of target+weight (E,ht,wd,2)x2
         import torch.distributed as dist
         mine = torch.randn(E, H1, W1, 4, device=dev)
         allv = torch.empty(world * E, H1, W1, 4, device=dev)
@@ -306,7 +307,7 @@ def main():
         if exchange:
             res["exchange"] = exchange
         print(json.dumps(res, ensure_ascii=False))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

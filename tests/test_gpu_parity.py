@@ -408,6 +408,54 @@ def test_torch_ops_namespace(lgu):
     assert isinstance(a, (list, tuple)) and torch.equal(a[0], b[0])
 
 
+def test_baseline_config1_plumbing_case(lgu, oracle):
+    """BASELINE config 1: single frame pair, 30x40 fmap, 1 pyramid level, r=3 — full oracle check
+    (W1 = 40 is 2.5 tiles of 16; the dispatcher picks 16-pixel tiles here)."""
+    case = inputs.pyramid_case(101, 1, 30, 40, 1, 3, 3.0, 4.0, True)
+    want, _ = oracle_pyramid(oracle, case, 3)
+    got, _ = run_pyramid(lgu, case, 3, 0)
+    assert got.shape == (1, 49, 30, 40) and np.abs(got - want).max() <= 1e-6
+
+
+def test_radius_above_three_uses_generic_kernel(lgu, oracle):
+    for radius in (4, 5):
+        case = inputs.pyramid_case(110 + radius, 1, 12, 16, 2, radius, 3.0, 4.0, True)
+        want, _ = oracle_pyramid(oracle, case, radius)
+        got, _ = run_pyramid(lgu, case, radius, 0)
+        assert np.abs(got - want).max() <= 1e-6
+        v, c, off = case["volumes"][0], case["coords"], case["offsets"][0]
+        rd = 2 * radius + 1
+        g = np.random.default_rng(radius).standard_normal((1, rd, rd, 12, 16)).astype(np.float32)
+        vg_w, og_w = oracle.defCorr_index_backward(v, c, off.copy(), g, radius)
+        vg, og = lgu.ops.defCorr_index_backward(dev(v), dev(c), dev(off), dev(g), radius)
+        assert np.abs(host(vg) - vg_w).max() <= 1e-5 * max(1.0, np.abs(vg_w).max())
+        assert np.abs(host(og) - og_w).max() <= 1e-5 * max(1.0, np.abs(og_w).max())
+
+
+@pytest.mark.parametrize("E", [40, 48])
+def test_large_edge_counts_stereo_and_frontend_cap(lgu, E):
+    """BASELINE config 3 (~40 edges, stereo + temporal) and the frontend cap of 48 edges
+    (droid_frontend.py:13): 2.0 / 2.4 GB of pyramid — 64-bit slice addressing.  Checked by
+    agreement of the fused launch with per-level launches and with the generic kernel on the
+    LAST edges (highest addresses)."""
+    torch.manual_seed(E)
+    H1, W1, L, r = 48, 64, 4, 3
+    vols = [torch.randn(E, H1, W1, H1 >> l, W1 >> l, device="cuda") for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H1, device="cuda").float(), torch.arange(W1, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys])[None] + 3 * torch.randn(E, 2, H1, W1, device="cuda")).contiguous()
+    o0 = 4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda"))
+    o1 = (4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda")) + o0) / 2
+    out = lgu.ops.defcorr_pyramid_forward(vols, coords, [o0, o1, None, None], r)
+    tail = slice(E - 2, E)
+    os.environ["LGU_DEFCORR_VARIANT"] = "2"
+    gen = lgu.ops.defcorr_pyramid_forward([v[tail].contiguous() for v in vols], coords[tail].contiguous(),
+                                          [o0[tail].contiguous(), o1[tail].contiguous(), None, None], r)
+    os.environ.pop("LGU_DEFCORR_VARIANT")
+    assert torch.equal(out[tail], gen)
+    c0, = lgu.ops.defCorr_index_forward(vols[0], coords, o0, r)
+    assert torch.equal(c0.view(E, 49, H1, W1), out[:, :49])
+
+
 def test_full_size_properties(lgu):
     """BASELINE cfg2 size (E=20, 48x64, L=4, r=3): size-independent properties instead of
     a full oracle run — linearity in the volume, zero-offset == plain sampler, variant
