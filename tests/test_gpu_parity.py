@@ -399,6 +399,33 @@ def test_empty_edge_list(lgu):
     assert lgu.ops.altcorr_forward(z(0, 8, 16, 32), z(0, 8, 16, 32), z(0, 1, 8, 16, 2), 1)[0].shape == (0, 1, 9, 8, 16)
 
 
+def test_streams_and_graph_capture(lgu):
+    """Kernels are enqueued on torch's CURRENT stream (reference: legacy default stream only) and the
+    launch path makes no allocation / synchronisation, so a lookup can be captured in a HIP graph
+    and replayed (the update() hot loop is launch-bound around this kernel)."""
+    case = inputs.pyramid_case(121, 2, 24, 32, 3, 3, 3.0, 4.0, False)
+    vols = [dev(v) for v in case["volumes"]]
+    offs = [dev(o) if o is not None else None for o in case["offsets"]]
+    coords = dev(case["coords"])
+    want = lgu.ops.defcorr_pyramid_forward(vols, coords, offs, 3)
+    plan = lgu.ops.DefcorrPyramidPlan(vols, offs, 3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out_side = plan(coords)
+    side.synchronize()
+    assert torch.equal(out_side, want)
+    static_out = torch.zeros_like(want)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan(coords, out=static_out)
+    static_out.zero_()
+    coords.copy_(coords + 0.25)  # new inputs in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, lgu.ops.defcorr_pyramid_forward(vols, coords, offs, 3))
+
+
 def test_torch_ops_namespace(lgu):
     from lgu_slam_amd import torch_ops  # noqa: F401  (registers torch.ops.lgu.*)
     case = inputs.pyramid_case(81, 1, 12, 16, 1, 3, 3.0, 4.0, True)

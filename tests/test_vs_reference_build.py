@@ -144,3 +144,43 @@ def test_altcorr_vs_reference(lgu, refalt, cfg):
     r1, r2, r3 = refalt.altcorr_backward(f1, f2, c, g, r)
     m1, m2, m3 = lgu.ops.altcorr_backward(f1, f2, c, g, r)
     assert close(m1, r1) and close(m2, r2) and not bool(m3.any()) and not bool(r3.any())
+
+
+def test_non_finite_and_wild_coordinates_match_reference(lgu, ref):
+    """Reprojection can hand the lookup NaN / inf / huge coordinates (points behind the camera).
+    The reference's behaviour there is whatever float->int conversion the hardware does; both
+    builds run on the same device, so outputs must agree exactly (NaN positions included) and
+    nothing may fault."""
+    rng = np.random.default_rng(77)
+    E, H1, W1 = 1, 16, 32
+    case = inputs.pyramid_case(555, E, H1, W1, 2, 3, 3.0, 4.0, True)
+    c = case["coords"].copy()
+    c[0, 0, 0, :8] = np.nan
+    c[0, 1, 1, :8] = np.inf
+    c[0, 0, 2, :8] = -np.inf
+    c[0, :, 3, :8] = 3.0e9
+    c[0, :, 4, :8] = -3.0e9
+    c[0, 0, 5, :8] = 1e-40  # subnormal
+    vols = [dev(v) for v in case["volumes"]]
+    cd = dev(c)
+    for variant in ("0", "1", "2", "3"):
+        os.environ["LGU_DEFCORR_VARIANT"] = variant
+        try:
+            for l in range(2):
+                cl = (cd / 2 ** l).contiguous()
+                a, = ref.defCorr_index_forward(vols[l], cl, dev(case["offsets"][l]), 3)
+                b, = lgu.ops.defCorr_index_forward(vols[l], cl, dev(case["offsets"][l]), 3)
+                assert torch.equal(torch.isnan(a), torch.isnan(b)), (variant, l)
+                assert torch.allclose(a, b, rtol=0, atol=1e-6, equal_nan=True), (variant, l)
+        finally:
+            os.environ.pop("LGU_DEFCORR_VARIANT", None)
+    # low-memory path
+    fc = inputs.fmap_case(556, 2, 1, 8, 16, 8, 16, 64, 3, 3.0, 1.0)
+    cc = fc["coords"].copy()
+    cc[0, 0, 0, :4, 0] = np.nan
+    cc[0, 0, 1, :4, 1] = np.inf
+    cc[1, 0, 2, :4, :] = -2.5e9
+    a, = ref.lowMem_defSample(dev(fc["fmap1"]), dev(fc["fmap2"]), dev(cc), dev(fc["offset"]), 3)
+    b, = lgu.ops.lowMem_defSample(dev(fc["fmap1"]), dev(fc["fmap2"]), dev(cc), dev(fc["offset"]), 3)
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.allclose(a, b, rtol=0, atol=1e-5, equal_nan=True)
