@@ -92,3 +92,61 @@ def sharded_pyramid_sample(block_call, coords, rank, world, exchange=None):
     if exchange is None:
         return mine
     return exchange.gather(mine)
+
+
+class ShardedEdgeSet:
+    """Ownership bookkeeping for one sharded update step of the backend (low-memory) path.
+
+    The partition is a pure function of the edge list, so every rank builds the same object:
+    `chunks[r]` = the source-frame chunks (index tensors into the edge list) rank r processes,
+    `owned[r]` = their concatenation.  `gather(x_local)` all-gathers a per-edge tensor given in
+    this rank's `owned` order and returns it in the ORIGINAL edge order on every rank — what
+    dense BA consumes (reference factor_graph.py:290-300).
+    """
+
+    def __init__(self, ii, rank=None, world=None, chunk=8, group=None):
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rank, self.world = rank, world
+        self.chunks = chunk_shards(ii, world, chunk)
+        dev = ii.device
+        empty = torch.zeros(0, dtype=torch.long, device=dev)
+        self.owned = [torch.cat(c) if len(c) else empty for c in self.chunks]
+        self.counts = [int(o.numel()) for o in self.owned]
+        order = torch.cat(self.owned) if self.owned else empty   # edge ids in gathered (rank-major) order
+        self.inverse = torch.empty_like(order)
+        self.inverse[order] = torch.arange(order.numel(), device=dev)
+        self.exchange = EdgeExchange(self.counts, group) if (dist.is_initialized() or world == 1) else None
+
+    @property
+    def my_chunks(self):
+        return self.chunks[self.rank]
+
+    @property
+    def my_edges(self):
+        return self.owned[self.rank]
+
+    def gather(self, x_local):
+        allx = self.exchange.gather(x_local) if self.world > 1 else x_local
+        return allx[self.inverse.to(allx.device)]
+
+
+class ShardedAltCorr:
+    """The correlation step of update_lowmem (reference factor_graph.py:262-279) over this rank's
+    chunks: one AltCorrBlock over the (replicated) feature maps, looked up chunk by chunk exactly as
+    the reference iterates them, so every chunk equals a chunk of the single-GPU run."""
+
+    def __init__(self, ofsMap, ofs_residual, GA, fmaps, ii, jj, rig=1, rank=None, world=None, chunk=8, group=None):
+        from .corr import AltCorrBlock
+        self.block = AltCorrBlock(ofsMap, ofs_residual, GA, fmaps)
+        self.ii, self.jj, self.rig = ii, jj, rig
+        self.edges = ShardedEdgeSet(ii, rank, world, chunk, group)
+
+    def lookup(self, coords1):
+        """coords1 (1,E,H,W,2) for ALL edges (replicated).  Yields (edge_index_tensor, corr (1,n,196,H,W))
+        for each chunk this rank owns."""
+        for idx in self.edges.my_chunks:
+            iis, jjs = self.ii[idx], self.jj[idx]
+            yield idx, self.block(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long())

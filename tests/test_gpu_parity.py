@@ -352,6 +352,37 @@ def test_altcorrblock_matches_oracle_composition(lgu, oracle):
     assert np.abs(host(got)[0] - want).max() <= 2e-5
 
 
+def test_sharded_altcorr_world1_equals_unsharded(lgu):
+    """the sharded lookup driver on one rank visits the reference's own source-frame
+    chunks (factor_graph.py:272-276) and reproduces AltCorrBlock on each of them."""
+    torch.manual_seed(11)
+    N, C, H, W = 20, 128, 24, 32
+    dev_ = "cuda"
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    fmaps = torch.randn(1, N, C, H, W, device=dev_) * 0.5
+    ii = torch.tensor([0, 0, 1, 7, 8, 9, 15, 16, 16, 19], device=dev_)
+    jj = torch.tensor([1, 2, 0, 8, 7, 10, 16, 15, 17, 18], device=dev_)
+    E = ii.numel()
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev_).float(), torch.arange(W, device=dev_).float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, H, W, 2, device=dev_)
+    with torch.no_grad():
+        sh = lgu.sharded.ShardedAltCorr(ofsMap, ofsRes, None, fmaps, ii, jj, rank=0, world=1)
+        ref_blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        seen = []
+        feats = torch.zeros(E, 196, H, W, device=dev_)
+        for idx, corr in sh.lookup(coords):
+            want = ref_blk(coords[:, idx], ii[idx], jj[idx] + (ii[idx] == jj[idx]).long())
+            # (the offset convolutions are not bitwise reproducible call to call on every backend)
+            assert float((corr - want).abs().max()) <= 1e-5
+            assert int(ii[idx].max()) // 8 == int(ii[idx].min()) // 8
+            feats[idx] = corr[0]
+            seen += idx.tolist()
+        assert sorted(seen) == list(range(E))
+        local = feats[sh.edges.my_edges]
+        assert torch.equal(sh.edges.gather(local), feats)
+
+
 def test_autograd_functions_route_gradients(lgu, oracle):
     """a10: CorrSampler / DefCorrSampler / GaussianMaskCuda (reference corr.py:10-42,
     gaussianMask_cuda.py:7-23): grads for volume and offset (never coords), mean and cov (never corr)."""

@@ -153,3 +153,41 @@ def test_bench_distributed_control_flow_gloo_world2():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["exchange"]["bytes_per_rank"] == 20 * 48 * 64 * 4 * 4
     for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert k in d
+
+
+def test_sharded_edge_set_world1_orders(lgu):
+    ii = torch.tensor([9, 0, 0, 17, 1, 3, 8, 9, 17, 30, 31])
+    es = lgu.sharded.ShardedEdgeSet(ii, rank=0, world=1)
+    assert sorted(es.my_edges.tolist()) == list(range(ii.numel()))
+    x = torch.arange(ii.numel(), dtype=torch.float32)[:, None] * 10
+    assert torch.equal(es.gather(x[es.my_edges]), x)  # back in original edge order
+
+
+def _gloo_edge_set_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import lgu_slam_amd
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ii = torch.tensor([9, 0, 0, 17, 1, 3, 8, 9, 17, 30, 31, 40, 41, 2])
+        es = lgu_slam_amd.sharded.ShardedEdgeSet(ii)
+        full = torch.arange(ii.numel() * 2, dtype=torch.float32).view(-1, 2)
+        got = es.gather(full[es.my_edges])  # each rank contributes only what it owns
+        q.put((rank, bool(torch.equal(got, full)), es.counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_edge_set_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_gloo_edge_set_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and sum(res[0][2]) == 14
