@@ -9,25 +9,28 @@
 //   Every (edge, pixel) owns a private slice of H2*W2 floats per level; adjacent pixels
 //   share nothing, so the only reuse is among the rd*rd taps of one pixel.  The
 //   reference maps one thread per pixel (lane stride = one slice = 12 KiB at level 0:
-//   196 dependent 4-byte gathers per thread).  Here ONE WAVE serves one (pixel, level)
-//   job with LANES = TAPS:
-//     1. lane t loads its own offset pair (the pixel's rd*rd*2 floats are one contiguous
-//        coalesced read) and forms its tap's integer corner;
-//     2. a wave reduction gives the tap bounding box [ylo,yhi] x [xlo,xhi] of the slice;
-//     3. the wave copies that box — whole 16-byte granules of each touched row — into
-//        LDS, either by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) or through
-//        registers; every touched 128-byte line is requested exactly once;
-//     4. lane t blends its four corners from LDS and parks the result in an LDS
-//        transpose tile [channel][pixel];
-//   and a workgroup (4 waves x 4 pixels x L levels = up to 16 jobs per wave, all loads
-//   issued before the first is consumed) finally writes the tile out with 64-byte
-//   coalesced segments straight into the concatenated (E, L*rd*rd, H1, W1) tensor.
-//   Jobs whose box does not fit the wave's LDS pool fall back to direct gathers.
+//   196 dependent 4-byte gathers per thread).  Here one WAVE serves a (pixel, level) job:
+//     * levels with offsets: LANES = TAPS — lane t loads its own offset pair (the pixel's
+//       rd*rd*2 floats are one coalesced read) and its four corners; the ~15-20 lines a
+//       pixel touches are shared by the 49 lanes of each corner load;
+//     * zero-offset levels: LANES = LATTICE POINTS — all taps share one fractional part and
+//       sit on a (2r+2)^2 integer lattice = one wave; one 4-byte load per lane, taps pull
+//       their corners with ds_bpermute;
+//   a workgroup covers 32 (or 16) x-adjacent pixels, issues every load of its jobs before
+//   the first is consumed, blends in the reference's fp32 order, parks results in an LDS
+//   transpose tile [channel][pixel] and writes full 128-byte rows straight into the
+//   concatenated (E, L*rd*rd, H1, W1) tensor.  The uncertainty probe of corr.py:94-99 is
+//   optionally fused.  Kernels in this file:
+//     defcorr_gather_kernel   production (register gather)                  [variant 0/3/4/5]
+//     defcorr_pyr_kernel      LDS-DMA staged variant: tap box by packed DPP reduction,
+//                             global_load_lds_dwordx4 into an LDS pool — same HBM bytes,
+//                             1.8x the instructions, kept for A/B              [variant 1]
+//     defcorr_generic_kernel  one thread per output: any radius / shape         [variant 2]
 #include "lgu_common.hpp"
 
 namespace lgu {
 
-constexpr int TP = 16;               // pixels (along x) per workgroup
+constexpr int TP = 16;               // pixels (along x) per workgroup of the staged kernel / narrow gather tiles
 constexpr int NWAVE = 4;             // waves per workgroup
 constexpr int PPW = TP / NWAVE;      // pixels per wave
 constexpr int FASTL = 4;             // levels served by one launch of the fast kernel

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 output of tools/gpu_run7.sh (gpurun_out/prof_{trace,fetch,write}) into the
+"""Turns the raw rocprofv3 output of tools/gpu_full_run.sh (gpurun_out/prof_{trace,fetch,write}) into the
 small tracked summaries under profiles/: kernel-stats CSV (top rows), PMC traffic JSON (with the gfx950
 FETCH_SIZE correction) and one combined JSON with the bench lines and the reference comparison."""
 import csv
@@ -59,7 +59,7 @@ csv.writer(open(os.path.join(P, "%s_kernel_stats.csv" % tag), "w")).writerows([r
 b = json.load(open(os.path.join(G, "bench.json")))
 bp = json.load(open(os.path.join(G, "bench_probe.json")))
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
-json.dump({"note": "tools/gpu_run7.sh on one MI355X box: default bench.py, bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic, "
+json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py, bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic, "
                    "comparison with the reference kernels (oracle/_ref) on the same device",
            "bench": b, "bench_probe": {k: bp[k] for k in ("value", "ms_per_step", "roofline")},
            "kernel_stats_defcorr": {k: kern[k] for k in kern}, "traffic": traffic, "compare_ref": cmp_},
