@@ -137,6 +137,20 @@ int lgu_altcorr_bwd_f32(const float* fmap1, const float* fmap2, const float* coo
                         int B, int S, int H1, int W1, int H2, int W2, int C,
                         int radius, void* stream);
 
+/* Mixed-precision forms of the two low-memory forward operators: feature maps in IEEE half
+ * (as droid_slam/depth_video.py stores them), everything else — coords, offsets, products,
+ * sums, output — fp32.  Bit-identical to calling the _f32 entry on fmap.float(): the reference
+ * call sites (droid_slam/modules/corr.py:202,209) do exactly that conversion first; these entries
+ * skip the conversion passes and stage half the bytes.  Same shapes/side effects as the _f32
+ * forms; require C % 16 == 0 and radius in 1..3, otherwise LGU_E_UNSUPPORTED. */
+int lgu_lowmem_defsample_fwd_h16(const void* fmap1_half, const void* fmap2_half, const float* coords,
+                                 float* offset, float* corr,
+                                 int B, int S, int H1, int W1, int H2, int W2, int C, int NO,
+                                 int radius, void* stream);
+int lgu_altcorr_fwd_h16(const void* fmap1_half, const void* fmap2_half, const float* coords, float* corr,
+                        int B, int S, int H1, int W1, int H2, int W2, int C,
+                        int radius, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,19 +230,37 @@ class AltCorrBlock:
         feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float()
         self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
 
-        f1 = f1.float().contiguous()
+        # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
+        # operators accumulate in fp32 and equal the reference's `.float()` call sites bit for bit.
+        mixed = f1.dtype == torch.float16
+        f1 = f1.contiguous() if mixed else f1.float().contiguous()
         out = []
         for i in range(self.num_levels):
             f2 = self.pyramid[i][:, jj]
-            f2 = f2.reshape((B * N,) + f2.shape[2:]).float().contiguous()
+            f2 = f2.reshape((B * N,) + f2.shape[2:])
+            f2 = f2.contiguous() if mixed else f2.float().contiguous()
             coords_i = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
+            use_mixed = mixed
             if i == 1:
-                probe, = ops.altcorr_forward(f1, f2, coords_i, 1)
+                if use_mixed:
+                    try:
+                        probe, = ops.altcorr_forward_mixed(f1, f2, coords_i, 1)
+                    except _lib.UnsupportedShape:
+                        use_mixed = False
+                if not use_mixed:
+                    probe, = ops.altcorr_forward(f1.float(), f2.float(), coords_i, 1)
                 probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)  # needs B = S = 1, as in the reference
                 mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
                 self.offset[1] = self.offset[1] * mask
             off = self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
-            corr, = ops.lowMem_defSample(f1, f2, coords_i, off, self.radius)
+            corr = None
+            if use_mixed:
+                try:
+                    corr, = ops.lowMem_defSample_mixed(f1, f2, coords_i, off, self.radius)
+                except _lib.UnsupportedShape:
+                    corr = None
+            if corr is None:
+                corr, = ops.lowMem_defSample(f1.float(), f2.float(), coords_i, off, self.radius)
             out.append(corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
         return torch.cat(out, dim=2)
 

@@ -42,14 +42,36 @@ constexpr int LT_OUTP = LT_PIX + 1;
 constexpr int LT_SCMAX = 4;                               // chunks staged per barrier pair when the window is small
 
 
-template <int R>
-__global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const float* __restrict__ fmap1,
-                                                                       const float* __restrict__ fmap2,
+// T = feature-map element type: float, or _Float16 (features kept in half precision as the
+// SLAM system stores them; products and sums stay fp32, i.e. exactly what the reference call site
+// `lowMem_defSample(fmap1.float(), fmap2.float(), ...)` computes, without the conversion passes and
+// with half the LDS bytes per multiply-add).  One staged "piece" is 16 bytes = EPP elements.
+template <typename T>
+__device__ __forceinline__ float piece_dot(const float4& fa, const float4& va, float s);
+template <>
+__device__ __forceinline__ float piece_dot<float>(const float4& f, const float4& a, float s) {
+  s = __builtin_fmaf(f.x, a.x, s); s = __builtin_fmaf(f.y, a.y, s);
+  s = __builtin_fmaf(f.z, a.z, s); s = __builtin_fmaf(f.w, a.w, s);
+  return s;
+}
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <>
+__device__ __forceinline__ float piece_dot<_Float16>(const float4& f, const float4& a, float s) {
+  const half8_t fh = __builtin_bit_cast(half8_t, f), ah = __builtin_bit_cast(half8_t, a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)fh[i], (float)ah[i], s);  // channel order, fp32 accumulate
+  return s;
+}
+
+template <int R, typename T>
+__global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const T* __restrict__ fmap1,
+                                                                       const T* __restrict__ fmap2,
                                                                        const float* __restrict__ coords, float* offset,
                                                                        float* __restrict__ corr, int B, int S, int H1,
                                                                        int W1, int H2, int W2, int C, int tiles_x,
                                                                        int tiles_y) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
+  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   extern __shared__ float4 smem4[];
   float* const stage = reinterpret_cast<float*>(smem4);       // [positions][pitch], LT_STAGE_FLOATS
   float* const dscr = stage + 4096;                           // [LT_WAVES][LT_MAXBOX] patch scratch, aliases the stage too
@@ -68,8 +90,8 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   const int b = bid / tiles_y;
   const int n = blockIdx.y;
   const size_t HW1 = (size_t)H1 * W1;
-  const float* F2 = fmap2 + (size_t)b * H2 * W2 * C;
-  const float* F1 = fmap1 + (size_t)b * H1 * W1 * C;  // per-edge bases keep the 32-bit offsets below small
+  const T* F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  const T* F1 = fmap1 + (size_t)b * H1 * W1 * C;  // per-edge bases keep the 32-bit offsets below small
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
   // offset == nullptr: plain (zero-offset) sampling = altcorr_forward (src/altcorr_kernel.cu:27-149)
   float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
@@ -160,17 +182,18 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   }
 
   // ---- phase 1: stage the window chunk by chunk, accumulate every pixel's patch ----
-  // The channel chunk is 16 floats (80-byte position pitch) when the padded window fits the stage
-  // at that pitch and 8 floats (48-byte pitch, conflict-free by the same argument) for larger
-  // windows: the stage holds LT_STAGE_FLOATS either way.
-  auto chunk_loop = [&](auto ch_tag) __attribute__((always_inline)) {
-    constexpr int CH = decltype(ch_tag)::value;
-    constexpr int Q4 = CH / 4, PITCH = CH + 4;
+  // A staged position holds 4 pieces (64 B of channels, 80-byte pitch) when the padded window fits
+  // the stage at that pitch and 2 pieces (48-byte pitch, conflict-free by the same argument) for
+  // larger windows: the stage holds LT_STAGE_FLOATS either way.
+  auto chunk_loop = [&](auto pc_tag) __attribute__((always_inline)) {
+    constexpr int Q4 = decltype(pc_tag)::value;  // 16-byte pieces per staged position: 4 (80-byte pitch) or 2 (48-byte pitch)
+    constexpr int CH = Q4 * EPP;                  // channels per chunk
+    constexpr int PITCH = Q4 * 4 + 4;             // floats per staged position
     constexpr int CAP = LT_STAGE_FLOATS / PITCH;  // positions the stage holds at this pitch
     const float rUW = 1.0f / (float)UWp;
     // small windows (coarse pyramid levels): stage SC chunks per barrier pair
     int SC = 1;
-    if (npos * 4 <= CAP && C % (CH * 4) == 0 && CH * 4 <= LT_CH * LT_SCMAX) SC = 4;
+    if (npos * 4 <= CAP && C % (CH * 4) == 0 && Q4 * 4 <= 4 * LT_SCMAX) SC = 4;
     else if (npos * 2 <= CAP && C % (CH * 2) == 0) SC = 2;
     const int nvp = npos * SC;  // virtual positions: (sub-chunk, position)
     const float rnpos = 1.0f / (float)npos;
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
     if (tid < LT_PIX * Q4 * SC) {  // fmap1 chunk(s) of the tile's 64 pixels (read back as LDS broadcasts)
       const int pw = tid / (Q4 * SC);
       const int h1 = ty * LT_H + (pw >> 4), w1 = tx * LT_W + (pw & 15);
-      if (h1 < H1 && w1 < W1) f1off = (h1 * W1 + w1) * C + (tid - pw * Q4 * SC) * 4;
+      if (h1 < H1 && w1 < W1) f1off = (h1 * W1 + w1) * C + (tid - pw * Q4 * SC) * EPP;
     }
     if (f1off >= 0) pf1 = *reinterpret_cast<const float4*>(F1 + f1off);
 #pragma unroll
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
       const int pos = vp - sc * npos;
       const int uy = (int)(((float)pos + 0.5f) * rUW);
       const int ux = pos - uy * UWp;
-      soff[i] = (idx < nvp * Q4 && ux < UW) ? ((UY0 + uy) * W2 + (UX0 + ux)) * C + sc * CH + (idx % Q4) * 4 : -1;
+      soff[i] = (idx < nvp * Q4 && ux < UW) ? ((UY0 + uy) * W2 + (UX0 + ux)) * C + sc * CH + (idx % Q4) * EPP : -1;
       pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (soff[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(F2 + soff[i]);  // chunk 0
     }
@@ -224,18 +247,15 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
           if (h1 >= H1 || w1 >= W1) continue;  // wave-uniform
           float4 f1[Q4];  // same address in every lane: LDS broadcast
 #pragma unroll
-          for (int i = 0; i < Q4; i++) f1[i] = *reinterpret_cast<const float4*>(f1s + (pw * SC + sc) * CH + i * 4);
+          for (int i = 0; i < Q4; i++) f1[i] = *reinterpret_cast<const float4*>(f1s + ((pw * SC + sc) * Q4 + i) * 4);
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const unsigned ps = (lpos[k][j >> 1] >> (16 * (j & 1))) & 0xffffu;
             if (ps != 0xffffu) {
               float s = acc[k][j];
 #pragma unroll
-              for (int i = 0; i < Q4; i++) {
-                const float4 a = *reinterpret_cast<const float4*>(stg + ps * PITCH + i * 4);
-                s = __builtin_fmaf(f1[i].x, a.x, s); s = __builtin_fmaf(f1[i].y, a.y, s);
-                s = __builtin_fmaf(f1[i].z, a.z, s); s = __builtin_fmaf(f1[i].w, a.w, s);
-              }
+              for (int i = 0; i < Q4; i++)
+                s = piece_dot<T>(f1[i], *reinterpret_cast<const float4*>(stg + ps * PITCH + i * 4), s);
               acc[k][j] = s;
             }
           }
@@ -245,8 +265,8 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
     __syncthreads();  // the stage is dead from here on: it becomes the output tile
   };
   if (tiled) {
-    if (npos <= LT_STAGE_FLOATS / (16 + 4) && C % 16 == 0) chunk_loop(std::integral_constant<int, 16>{});
-    else chunk_loop(std::integral_constant<int, 8>{});
+    if (npos <= LT_STAGE_FLOATS / 20 && C % (4 * EPP) == 0) chunk_loop(std::integral_constant<int, 4>{});
+    else chunk_loop(std::integral_constant<int, 2>{});
   }
 
   // ---- phase 2: sample every pixel's patch (or fall back to per-tap dots) ----
@@ -288,21 +308,14 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
       }
     } else if (tap) {
       // fallback: this lane's four corner dots, channels in order
-      const float* f1p = fmap1 + (((size_t)b * H1 + h1) * W1 + w1) * C;
-      const float* p11 = F2 + ((ptrdiff_t)h2 * W2 + w2) * C;
-      for (int c = 0; c < C; c += 4) {
+      const T* f1p = F1 + ((size_t)h1 * W1 + w1) * C;
+      const T* p11 = F2 + ((ptrdiff_t)h2 * W2 + w2) * C;
+      for (int c = 0; c < C; c += EPP) {
         const float4 f = *reinterpret_cast<const float4*>(f1p + c);
-#define LGU_DOT4(acc_, ptr_)                                                         \
-  {                                                                                  \
-    const float4 v_ = *reinterpret_cast<const float4*>(ptr_);                        \
-    acc_ = __builtin_fmaf(f.x, v_.x, acc_); acc_ = __builtin_fmaf(f.y, v_.y, acc_); \
-    acc_ = __builtin_fmaf(f.z, v_.z, acc_); acc_ = __builtin_fmaf(f.w, v_.w, acc_); \
-  }
-        if (b11) LGU_DOT4(q11, p11 + c)
-        if (b21) LGU_DOT4(q21, p11 + C + c)
-        if (b12) LGU_DOT4(q12, p11 + (size_t)W2 * C + c)
-        if (b22) LGU_DOT4(q22, p11 + (size_t)W2 * C + C + c)
-#undef LGU_DOT4
+        if (b11) q11 = piece_dot<T>(f, *reinterpret_cast<const float4*>(p11 + c), q11);
+        if (b21) q21 = piece_dot<T>(f, *reinterpret_cast<const float4*>(p11 + C + c), q21);
+        if (b12) q12 = piece_dot<T>(f, *reinterpret_cast<const float4*>(p11 + (size_t)W2 * C + c), q12);
+        if (b22) q22 = piece_dot<T>(f, *reinterpret_cast<const float4*>(p11 + (size_t)W2 * C + C + c), q22);
       }
     }
     if (tap) outt[lane * LT_OUTP + pw] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
@@ -317,11 +330,11 @@ __global__ __launch_bounds__(LT_WAVES * kWave) void lowmem_tile_kernel(const flo
   }
 }
 
-template <int R>
-static int launch_tile(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
-                       int S, int H1, int W1, int H2, int W2, int C, hipStream_t st) {
+template <int R, typename T>
+static int launch_tile(const T* fmap1, const T* fmap2, const float* coords, float* offset, float* corr, int B, int S,
+                       int H1, int W1, int H2, int W2, int C, hipStream_t st) {
   const size_t lds = sizeof(float) * ((size_t)LT_STAGE_FLOATS + LT_PIX * 4 + 8 + LT_PIX * LT_CH * LT_SCMAX);
-  auto kern = lowmem_tile_kernel<R>;
+  auto kern = lowmem_tile_kernel<R, T>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -333,17 +346,56 @@ static int launch_tile(const float* fmap1, const float* fmap2, const float* coor
   return launch_status();
 }
 
-// Called from lgu_lowmem_defsample_fwd_f32 (lowmem.hip).  Returns -1 when this kernel does
-// not serve the arguments (the caller then uses the wave-per-pixel kernel).
-int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
-                         int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+template <typename T>
+static int tile_dispatch(const T* fmap1, const T* fmap2, const float* coords, float* offset, float* corr, int B, int S,
+                         int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
   const bool aligned = ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
-  if (radius < 1 || radius > 3 || C % 8 != 0 || !aligned || S > 65535) return -1;
+  constexpr int epp = 16 / (int)sizeof(T);
+  if (radius < 1 || radius > 3 || C % (2 * epp) != 0 || !aligned || S > 65535) return -1;
+  if ((size_t)H2 * W2 * C >= (1u << 31) || (size_t)H1 * W1 * C >= (1u << 31)) return -1;  // 32-bit offsets inside one edge
   switch (radius) {
-    case 1: return launch_tile<1>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
-    case 2: return launch_tile<2>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
-    default: return launch_tile<3>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+    case 1: return launch_tile<1, T>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+    case 2: return launch_tile<2, T>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
+    default: return launch_tile<3, T>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, st);
   }
 }
 
+// Called from lgu_lowmem_defsample_fwd_f32 / lgu_altcorr_fwd_f32 (lowmem.hip).  Returns -1 when this
+// kernel does not serve the arguments (the caller then uses the wave-per-pixel kernel).
+int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
+                         int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  return tile_dispatch<float>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
+}
+
 }  // namespace lgu
+
+extern "C" {
+
+// Mixed-precision entry points: fp16 feature maps, fp32 coords / offsets / accumulation / output.
+// Numerically these ARE the reference call sites `lowMem_defSample(fmap1.float(), fmap2.float(), ...)`
+// (droid_slam/modules/corr.py:209) and `altcorr_forward(fmap1.float(), fmap2.float(), ...)` (:202) for
+// feature maps stored in half precision, as droid_slam/depth_video.py keeps them.
+int lgu_lowmem_defsample_fwd_h16(const void* fmap1, const void* fmap2, const float* coords, float* offset, float* corr,
+                                 int B, int S, int H1, int W1, int H2, int W2, int C, int NO, int radius, void* stream) {
+  if (!fmap1 || !fmap2 || !coords || !offset || !corr) return LGU_E_BADARG;
+  if (B < 0 || S < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
+  if ((long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
+  if (B == 0) return LGU_OK;
+  const int rc = lgu::tile_dispatch<_Float16>(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2),
+                                              coords, offset, corr, B, S, H1, W1, H2, W2, C, radius,
+                                              reinterpret_cast<hipStream_t>(stream));
+  return rc < 0 ? LGU_E_UNSUPPORTED : rc;
+}
+
+int lgu_altcorr_fwd_h16(const void* fmap1, const void* fmap2, const float* coords, float* corr, int B, int S, int H1,
+                        int W1, int H2, int W2, int C, int radius, void* stream) {
+  if (!fmap1 || !fmap2 || !coords || !corr) return LGU_E_BADARG;
+  if (B < 0 || S < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
+  if (B == 0) return LGU_OK;
+  const int rc = lgu::tile_dispatch<_Float16>(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2),
+                                              coords, nullptr, corr, B, S, H1, W1, H2, W2, C, radius,
+                                              reinterpret_cast<hipStream_t>(stream));
+  return rc < 0 ? LGU_E_UNSUPPORTED : rc;
+}
+
+}  // extern "C"

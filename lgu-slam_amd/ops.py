@@ -17,6 +17,15 @@ from . import _lib
 _vp = ctypes.c_void_p
 
 
+def _check_dtype(t, name, dtype):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a HIP device tensor: lgu_slam_amd has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("expected scalar type %s but found %s (%s)" % (str(dtype).replace("torch.", ""), str(t.dtype).replace("torch.", ""), name))
+
+
 def _check(*named):
     """_check(volume, "volume", coords, "coords", ...): the reference's CHECK_INPUT on every
     argument first (TORCH_CHECK(x.is_contiguous(), #x " must be contiguous"), droid.cpp:48-49),
@@ -174,6 +183,43 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
                                              _stream(fmap1))
     _lib.check(rc, "altcorr_backward")
     return [fmap1_grad, fmap2_grad, coords_grad]
+
+
+def lowMem_defSample_mixed(fmap1, fmap2, coords, offset, radius):
+    """lowMem_defSample on HALF-precision feature maps with fp32 accumulation and output: bit-identical
+    to `lowMem_defSample(fmap1.float(), fmap2.float(), coords, offset, radius)` — which is what the
+    reference call site does (corr.py:209) — without materialising the float copies."""
+    _check_dtype(fmap1, "fmap1", torch.float16); _check_dtype(fmap2, "fmap2", torch.float16)
+    _check(coords, "coords", offset, "offset")
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    rd = 2 * radius + 1
+    corr = torch.empty((B, S, rd, rd, H1, W1), dtype=torch.float32, device=fmap1.device)
+    if B == 0:
+        return [corr]
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_lowmem_defsample_fwd_h16(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(offset), _ptr(corr),
+                                                      B, S, H1, W1, H2, W2, C, offset.shape[0], radius, _stream(fmap1))
+    _lib.check(rc, "lowMem_defSample_mixed")
+    return [corr]
+
+
+def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
+    """altcorr_forward on HALF-precision feature maps, fp32 accumulation/output (= the reference call
+    site corr.py:202 on `.float()` copies, bit for bit)."""
+    _check_dtype(fmap1, "fmap1", torch.float16); _check_dtype(fmap2, "fmap2", torch.float16)
+    _check(coords, "coords")
+    B, S, H1, W1, _ = coords.shape
+    _, H2, W2, C = fmap2.shape
+    rd = 2 * radius + 1
+    corr = torch.empty((B, S, rd * rd, H1, W1), dtype=torch.float32, device=fmap1.device)
+    if B == 0:
+        return [corr]
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_altcorr_fwd_h16(_ptr(fmap1), _ptr(fmap2), _ptr(coords), _ptr(corr), B, S, H1, W1, H2, W2, C,
+                                             radius, _stream(fmap1))
+    _lib.check(rc, "altcorr_forward_mixed")
+    return [corr]
 
 
 def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None):

@@ -352,6 +352,50 @@ def test_altcorrblock_matches_oracle_composition(lgu, oracle):
     assert np.abs(host(got)[0] - want).max() <= 2e-5
 
 
+@pytest.mark.parametrize("cfg", [(2, 1, 60, 80, 60, 80, 128, 3, 3.0, 1.0, 4.0), (2, 1, 60, 80, 30, 40, 128, 3, 3.0, 0.5, 4.0),
+                                 (1, 1, 24, 32, 6, 8, 64, 3, 3.0, 0.25, 4.0), (1, 1, 24, 32, 24, 32, 32, 3, 3.0, 1.0, 14.0),
+                                 (1, 2, 8, 16, 8, 16, 64, 1, 3.0, 1.0, 2.0)])
+def test_mixed_precision_lowmem_is_bitwise_the_float_call_site(lgu, oracle, cfg):
+    """lgu_*_h16: half feature maps, fp32 math.  Must equal the f32 operator on `.float()` copies —
+    the reference call sites corr.py:202,209 — BIT FOR BIT, and therefore the oracle to 1e-5."""
+    B, S, H1, W1, H2, W2, C, radius, sigma, scale, osc = cfg
+    case = inputs.fmap_case(400 + H2 + C, B, S, H1, W1, H2, W2, C, radius, sigma, scale, off_scale=osc)
+    f1h, f2h = dev(case["fmap1"]).half(), dev(case["fmap2"]).half()
+    coords = dev(case["coords"])
+    o_m, o_f = dev(case["offset"]), dev(case["offset"])
+    got, = lgu.ops.lowMem_defSample_mixed(f1h, f2h, coords, o_m, radius)
+    want, = lgu.ops.lowMem_defSample(f1h.float(), f2h.float(), coords, o_f, radius)
+    assert got.dtype == torch.float32 and torch.equal(got, want) and torch.equal(o_m, o_f)
+    ref_np, = oracle.lowMem_defSample(host(f1h.float()), host(f2h.float()), case["coords"], case["offset"].copy(), radius)
+    assert np.abs(host(got) - ref_np).max() <= 1e-5
+    a, = lgu.ops.altcorr_forward_mixed(f1h, f2h, coords, 1)
+    b, = lgu.ops.altcorr_forward(f1h.float(), f2h.float(), coords, 1)
+    assert torch.equal(a, b)
+
+
+def test_altcorrblock_half_features_equal_float_features(lgu):
+    """AltCorrBlock over a half-precision feature buffer (video.fmaps is torch.half) takes the mixed
+    operators and returns exactly what the float-converted path returns."""
+    torch.manual_seed(6)
+    N, C, H, W = 4, 128, 24, 32
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    fm = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ii = torch.tensor([0, 0, 1, 2], device="cuda")
+    jj = torch.tensor([1, 2, 3, 0], device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, 4, H, W, 2, device="cuda")
+    with torch.no_grad():
+        a = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
+        got = a(coords, ii, jj)
+        assert a.pyramid[0].dtype == torch.float16
+        b = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
+        b.pyramid = [p.float() for p in b.pyramid]   # float copies of the SAME half values
+        want = b(coords, ii, jj)
+    assert got.shape == (1, 4, 196, H, W)
+    assert float((got - want).abs().max()) <= 1e-5   # offsets come from convs that are not bitwise reproducible
+
+
 def test_sharded_altcorr_world1_equals_unsharded(lgu):
     """the sharded lookup driver on one rank visits the reference's own source-frame
     chunks (factor_graph.py:272-276) and reproduces AltCorrBlock on each of them."""
