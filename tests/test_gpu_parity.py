@@ -373,6 +373,28 @@ def test_mixed_precision_lowmem_is_bitwise_the_float_call_site(lgu, oracle, cfg)
     assert torch.equal(a, b)
 
 
+def test_lowmem_backend_scale_tile_kernel_equals_wave_kernel(lgu):
+    """BASELINE config 5 scale per GPU (250 edges x 60x80, C=128; here B=192 to bound the test's
+    memory): the tile-staged kernel and the independent wave-per-pixel kernel agree on the LAST edges
+    (largest addresses) — guards the 32-bit in-edge offsets and the grid decomposition."""
+    torch.manual_seed(13)
+    B, H, W, C = 192, 60, 80, 128
+    f1 = torch.randn(B, H, W, C, device="cuda") * 0.125
+    f2 = torch.randn(B, H // 2, W // 2, C, device="cuda") * 0.125
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = ((torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, device="cuda")) / 2).contiguous()
+    off = (4 * torch.tanh(torch.randn(1, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    got, = lgu.ops.lowMem_defSample(f1, f2, coords, off, 3)
+    tail = slice(B - 2, B)
+    os.environ["LGU_LOWMEM_VARIANT"] = "1"
+    try:
+        want, = lgu.ops.lowMem_defSample(f1[tail].contiguous(), f2[tail].contiguous(), coords[tail].contiguous(), off, 3)
+    finally:
+        os.environ.pop("LGU_LOWMEM_VARIANT")
+    assert float((got[tail] - want).abs().max()) <= 1e-5
+    assert torch.isfinite(got).all()
+
+
 def test_altcorrblock_half_features_equal_float_features(lgu):
     """AltCorrBlock over a half-precision feature buffer (video.fmaps is torch.half) takes the mixed
     operators and returns exactly what the float-converted path returns."""
