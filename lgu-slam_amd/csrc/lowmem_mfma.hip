@@ -1,0 +1,393 @@
+// lowmem_mfma.hip — on-the-fly deformable correlation from HALF feature maps on the matrix cores.
+//
+// Serves the mixed-precision entry points lgu_lowmem_defsample_fwd_h16 / lgu_altcorr_fwd_h16, i.e. the
+// reference call sites lowMem_defSample(fmap1.float(), fmap2.float(), ...) (droid_slam/modules/corr.py:209)
+// and altcorr_forward(fmap1.float(), fmap2.float(), ...) (:202) for feature maps the SLAM system stores
+// in half precision.  Kernels replaced: offersample_LGS/lowMem_defSample.cu:27-134,
+// src/altcorr_kernel.cu:27-149.
+//
+// Unlike the volume path this operator IS a contraction: dot(fmap1[p], bilerp(fmap2)(x,y)) equals the
+// bilinear blend of the four corner dots, so a pixel's 49 taps only need its LOCAL correlation patch
+//     D_p[y2][x2] = sum_c fmap1[p][c] * fmap2[y2][x2][c]     over its tap box (<= 16x16 positions)
+// and neighbouring pixels' boxes overlap almost entirely.  One WAVE owns a 4x4 pixel block:
+//   0. lanes = taps: tap box of each of the 16 pixels (packed DPP min/max), their union = the block window;
+//   1. the window is swept in groups of 16 x-adjacent positions: v_mfma_f32_16x16x32_f16 with
+//      A = fmap1 of the 16 pixels (resident in registers for the whole sweep, K = C channels in C/32 steps),
+//      B = fmap2 of the 16 positions, each lane loading 16 contiguous bytes of channels straight from the
+//      channel-last map (both operands are "k-contiguous per lane" in this layout: no LDS staging, no
+//      transposition).  Half products are exact in fp32 and the accumulation is fp32, so the result differs
+//      from the reference's `.float()` + fp32 chain by summation order only (tests: 1e-5).
+//      Each 16x16 result tile is scattered into the pixels' patches in LDS (only entries inside a pixel's box);
+//   2. lanes = taps again: the four corners come from the patch with the reference's per-corner zero
+//      padding (lowMem_defSample.cu:102-117), blended in its evaluation order, transposed through LDS
+//      and written as 16-byte row segments.
+// Every wave is independent (no workgroup barrier anywhere); a workgroup is 4 waves = an 8x8 pixel tile
+// so that neighbouring windows share L1/L2 lines, and edges are dealt to XCDs (workgroup id % 8) so one
+// edge's fmap2 (a few MB) stays in one XCD's L2.
+// Pixels whose box exceeds 16x16 (|offset| >= 4: never produced by corr.py:126-131) take a per-tap fallback.
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int MM_BP = 16;            // pixels per wave = 4 x 4 block (MFMA rows)
+constexpr int MM_BOX = 16;           // patch row pitch / largest box side
+constexpr int MM_PP = MM_BOX * MM_BOX + 4;  // patch pitch per pixel: the 4 pixel groups of one scatter land on different bank quarters
+constexpr int MM_OUTP = 20;          // output transpose pitch (16 pixels + pad, 16-byte aligned rows)
+constexpr int MM_LDS_FLOATS = MM_BP * MM_PP + MM_BP * 4;
+
+__device__ __forceinline__ float dot8_h(const half8v& f, const half8v& a, float s) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
+  return s;
+}
+
+// Fallback for boxes larger than the patch: the four corner dots of one tap straight from memory.
+__device__ __noinline__ float4 corner_dots_h(const _Float16* f1p, const _Float16* p11, int C, int W2, int mask) {
+  float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+  for (int c = 0; c < C; c += 8) {
+    const half8v f = *reinterpret_cast<const half8v*>(f1p + c);
+    if (mask & 1) q11 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + c), q11);
+    if (mask & 2) q21 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + C + c), q21);
+    if (mask & 4) q12 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + (size_t)W2 * C + c), q12);
+    if (mask & 8) q22 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + (size_t)W2 * C + C + c), q22);
+  }
+  return make_float4(q11, q21, q12, q22);
+}
+
+// Packed (x low, y high) int16 min / max over each ROW of 16 lanes (every lane of the row gets the result).
+template <bool IS_MIN>
+__device__ __forceinline__ int row_pk_reduce(int v) {
+#define LGU_DPP_STEP(ctrl)                                                  \
+  {                                                                         \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false); \
+    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                               \
+  }
+  LGU_DPP_STEP(0xB1)   // quad_perm:[1,0,3,2]
+  LGU_DPP_STEP(0x4E)   // quad_perm:[2,3,0,1]
+  LGU_DPP_STEP(0x141)  // row_half_mirror
+  LGU_DPP_STEP(0x140)  // row_mirror
+#undef LGU_DPP_STEP
+  return v;
+}
+
+// Diagnostic builds only (tools/diag/run_mm_stamps.py defines LGU_MM_STAMPS): per-wave phase stamps.
+#ifdef LGU_MM_STAMPS
+__device__ unsigned long long* g_mm_stamps;  // [wave][8]
+#define MM_STAMP(i)                                                                                \
+  do {                                                                                             \
+    if (lane == 0 && blockIdx.y == 0) g_mm_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define MM_STAMP(i)
+#endif
+
+// One wave = one workgroup = one 4 x 4 pixel block.  Lane layout outside the sweep: row = lane / 16 is a
+// pixel of the current pass (pass q serves block row q: pixel k = 4 q + row), j = lane % 16 carries the
+// taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes reduce inside 16-lane rows with DPP only.
+template <int R, int KS>
+__global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
+    const _Float16* __restrict__ fmap1, const _Float16* __restrict__ fmap2, const float* __restrict__ coords,
+    float* offset, float* __restrict__ corr, int B, int S, int H1, int W1, int H2, int W2, int blocks_x, int blocks_y,
+    int xcd_map, int vec_out) {
+  constexpr int RD = 2 * R + 1, NT = RD * RD, C = 32 * KS;
+  constexpr int TI = (NT + 15) / 16;   // tap slots per lane
+  constexpr int CEN = R * RD + R;      // centre tap
+  constexpr int MM_PF = KS <= 4 ? 4 : 2;  // position groups in flight (16 bytes x KS per lane each)
+  extern __shared__ float smem[];
+  float* const patch = smem;                                          // [16][MM_PP]
+  int* const pbox = reinterpret_cast<int*>(smem + MM_BP * MM_PP);     // [16][xlo,ylo,bw,bh]
+  const int lane = threadIdx.x;
+  const int lx = lane & 15, lg = lane >> 4;
+
+  // ---- workgroup -> (edge, block) ----
+  int b, blk;
+  const int blocks = blocks_x * blocks_y;
+  if (xcd_map) {  // consecutive workgroup ids go to consecutive XCDs: keep an edge on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    b = (slot / blocks) * 8 + xcd;
+    blk = slot % blocks;
+    if (b >= B) return;
+  } else {
+    b = blockIdx.x / blocks;
+    blk = blockIdx.x % blocks;
+  }
+  const int n = blockIdx.y;
+  const int by = blk / blocks_x, bx = blk % blocks_x;
+  const size_t HW1 = (size_t)H1 * W1;
+  const _Float16* const F1 = fmap1 + (size_t)b * HW1 * C;
+  const _Float16* const F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets (altcorr)
+  float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+  const float2* const cbase = reinterpret_cast<const float2*>(coords) + ((size_t)b * S + n) * HW1;
+
+  MM_STAMP(0);
+  // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested first, consumed by the sweep
+  half8v a[KS];
+  {
+    int h1 = by * 4 + (lx >> 2), w1 = bx * 4 + (lx & 3);
+    h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
+    const _Float16* ap = F1 + ((size_t)h1 * W1 + w1) * C + 8 * lg;
+#pragma unroll
+    for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const half8v*>(ap + 32 * s);
+  }
+  // ---- phase 0: sample positions and tap boxes (4 pixels per pass, one per lane row) ----
+  const int w1r = bx * 4 + lg;  // this lane row's pixel column
+  int tix[TI], tiy[TI];         // offset / output index [ix][iy] of this lane's tap slots
+#pragma unroll
+  for (int i = 0; i < TI; i++) {
+    const int t = lx + 16 * i;
+    tix[i] = t / RD;
+    tiy[i] = t - tix[i] * RD;
+  }
+  float2 cvv[4], o0[4][TI];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int h1 = by * 4 + q;
+    const bool pv = h1 < H1 && w1r < W1;
+    const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
+    cvv[q] = cbase[pix];
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const int t = lx + 16 * i;
+      o0[q][i] = make_float2(0.f, 0.f);
+      if (obase && pv && t < NT && t != CEN) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
+      if (obase && pv && t == CEN) reinterpret_cast<float2*>(obase + pix * NT * 2)[t] = make_float2(0.f, 0.f);  // :80-81
+    }
+  }
+  int blo[4], bwh[4];  // per pass, row-uniform: packed (xlo, ylo); bw | bh << 8 (0 = no patch) | fallback << 16
+  int ulo = 0x7fff7fff, uhi = (int)0x80008000;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int h1 = by * 4 + q;
+    const bool pv = h1 < H1 && w1r < W1;
+    int lo = 0x7fff7fff, hi = (int)0x80008000;
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const float xs = cvv[q].x + o0[q][i].x, ys = cvv[q].y + o0[q][i].y;  // :82-83
+      const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
+      const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
+      const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
+      const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
+      lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
+      hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+    }
+    lo = row_pk_reduce<true>(lo);
+    hi = row_pk_reduce<false>(hi);
+    const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
+    const bool any = xhi >= xlo && yhi >= ylo;
+    const bool boxed = any && xhi - xlo < MM_BOX && yhi - ylo < MM_BOX;
+    ulo = boxed ? pk_min(ulo, lo) : ulo;
+    uhi = boxed ? pk_max(uhi, hi) : uhi;
+    blo[q] = lo;
+    bwh[q] = boxed ? (xhi - xlo + 1) | ((yhi - ylo + 1) << 8) : (any ? 1 << 16 : 0);
+    if (lx == 0) {
+      int* pb = pbox + (q * 4 + lg) * 4;
+      pb[0] = xlo; pb[1] = ylo;
+      pb[2] = boxed ? xhi - xlo + 1 : 0;
+      pb[3] = boxed ? yhi - ylo + 1 : 0;
+    }
+  }
+  // union over the four lane rows = the block window
+  ulo = pk_min(pk_min(__builtin_amdgcn_readlane(ulo, 0), __builtin_amdgcn_readlane(ulo, 16)),
+               pk_min(__builtin_amdgcn_readlane(ulo, 32), __builtin_amdgcn_readlane(ulo, 48)));
+  uhi = pk_max(pk_max(__builtin_amdgcn_readlane(uhi, 0), __builtin_amdgcn_readlane(uhi, 16)),
+               pk_max(__builtin_amdgcn_readlane(uhi, 32), __builtin_amdgcn_readlane(uhi, 48)));
+  const int UX0 = __builtin_amdgcn_readfirstlane(pk_lo(ulo)), UY0 = __builtin_amdgcn_readfirstlane(pk_hi(ulo));
+  const int UX1 = __builtin_amdgcn_readfirstlane(pk_lo(uhi)), UY1 = __builtin_amdgcn_readfirstlane(pk_hi(uhi));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  MM_STAMP(1);
+
+  // ---- phase 1: sweep the block window with the matrix cores, scatter into the patches ----
+  if (UX1 >= UX0 && UY1 >= UY0) {
+    // result register r of lane (lg, lx) is pixel 4*lg + r at window position gx0 + lx
+    int sbase[4], sxv[4], sylo[4], sbw[4], sbh[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int p = lg * 4 + r;
+      const int xlo = pbox[p * 4 + 0], ylo = pbox[p * 4 + 1];
+      sbw[r] = pbox[p * 4 + 2]; sbh[r] = pbox[p * 4 + 3];
+      sxv[r] = lx - xlo; sylo[r] = ylo;
+      sbase[r] = p * MM_PP - ylo * MM_BOX - xlo + lx;
+    }
+    const int ngx = (UX1 - UX0 + MM_BOX) >> 4;  // groups of 16 positions per window row
+    const int nit = ngx * (UY1 - UY0 + 1);
+    auto bptr = [&](int y, int gx0) {
+      int x = gx0 + lx;
+      x = x < W2 ? x : W2 - 1;  // padded positions re-read the last column; their results land in no box
+      return F2 + ((size_t)(y * W2 + x)) * C + 8 * lg;
+    };
+    // MM_PF groups in flight: slot j holds iteration it + j; it is refilled for it + j + MM_PF right after use.
+    // (The sweep is bound by the L2 -> CU read rate, ~70 GB/s per CU; a hand-counted s_waitcnt variant with
+    // unconditional loads kept more loads in flight and was not faster: profiles/README.md.)
+    half8v bq[MM_PF][KS];
+    int yl = UY0, gxl = UX0;  // load cursor
+#pragma unroll
+    for (int j = 0; j < MM_PF; j++) {
+      if (j < nit) {
+        const _Float16* p = bptr(yl, gxl);
+#pragma unroll
+        for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const half8v*>(p + 32 * s);
+        gxl += 16;
+        if (gxl > UX1) { gxl = UX0; yl++; }
+      }
+    }
+    MM_STAMP(2);
+    int y = UY0, gx0 = UX0;   // compute cursor
+    for (int it = 0; it < nit; it += MM_PF) {
+#pragma unroll
+      for (int j = 0; j < MM_PF; j++) {
+        if (it + j < nit) {  // wave-uniform
+          f32x4v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], bq[j][s], d, 0, 0, 0);
+          if (it + j + MM_PF < nit) {
+            const _Float16* p = bptr(yl, gxl);
+#pragma unroll
+            for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const half8v*>(p + 32 * s);
+            gxl += 16;
+            if (gxl > UX1) { gxl = UX0; yl++; }
+          }
+          const int yg = y * MM_BOX + gx0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const unsigned qx = (unsigned)(gx0 + sxv[r]), qy = (unsigned)(y - sylo[r]);
+            if (qx < (unsigned)sbw[r] && qy < (unsigned)sbh[r]) patch[sbase[r] + yg] = d[r];
+          }
+          gx0 += 16;
+          if (gx0 > UX1) { gx0 = UX0; y++; }
+        }
+      }
+    }
+  }
+  MM_STAMP(3);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- phase 2: sample the patches (same lane layout as phase 0) ----
+  {  // tap indices are recomputed (from a laundered lane id) rather than kept live across the sweep
+    int lxo = lx;
+    asm volatile("" : "+v"(lxo));
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const int t = lxo + 16 * i;
+      tix[i] = t / RD;
+      tiy[i] = t - tix[i] * RD;
+    }
+  }
+  float res[4][TI];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int h1 = by * 4 + q;
+    const bool pv = h1 < H1 && w1r < W1;
+    const int xlo = pk_lo(blo[q]), ylo = pk_hi(blo[q]);
+    const bool has_patch = (bwh[q] & 0xff) != 0, fallback = (bwh[q] >> 16) != 0;
+    const float* const Dp = patch + (q * 4 + lg) * MM_PP;
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const bool tv = pv && lx + 16 * i < NT;
+      const float xs = cvv[q].x + o0[q][i].x, ys = cvv[q].y + o0[q][i].y;
+      const float fxs = floorf(xs), fys = floorf(ys);
+      const float dx = xs - fxs, dy = ys - fys;  // :87-88
+      const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
+      const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
+      const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
+      float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+      if (tv && has_patch) {
+        const float* D = Dp + (h2 - ylo) * MM_BOX + (w2 - xlo);
+        if (b11) q11 = D[0];
+        if (b21) q21 = D[1];
+        if (b12) q12 = D[MM_BOX];
+        if (b22) q22 = D[MM_BOX + 1];
+      } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
+        const float4 qq = corner_dots_h(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
+                                        (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0));
+        q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+      }
+      res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  MM_STAMP(4);
+
+  // ---- write-out: corr[b][n][ix][iy][h1][w1]; the patch region becomes the [tap][pixel] transpose tile ----
+  float* const outt = patch;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+      if (lx + 16 * i < NT) outt[(lx + 16 * i) * MM_OUTP + q * 4 + lg] = res[q][i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* const cb = corr + ((size_t)b * S + n) * NT * HW1;
+  for (int idx = lane; idx < NT * 4; idx += kWave) {
+    const int t = idx >> 2, q = idx & 3;
+    const int h1 = by * 4 + q, w1 = bx * 4;
+    if (h1 >= H1) continue;
+    const float4 v = *reinterpret_cast<const float4*>(outt + t * MM_OUTP + q * 4);
+    float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
+    if (vec_out) {
+      *reinterpret_cast<float4*>(dst) = v;
+    } else {
+      dst[0] = v.x;
+      if (w1 + 1 < W1) dst[1] = v.y;
+      if (w1 + 2 < W1) dst[2] = v.z;
+      if (w1 + 3 < W1) dst[3] = v.w;
+    }
+  }
+  MM_STAMP(5);
+}
+
+template <int R, int KS>
+static int launch_mfma(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                       int B, int S, int H1, int W1, int H2, int W2, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)MM_LDS_FLOATS;
+  auto kern = lowmem_mfma_kernel<R, KS>;
+  const int blocks_x = (W1 + 3) / 4, blocks_y = (H1 + 3) / 4;
+  const int blocks = blocks_x * blocks_y;
+  const int xcd_map = B >= 8 ? 1 : 0;
+  const size_t nwg = xcd_map ? (size_t)((B + 7) / 8) * 8 * blocks : (size_t)B * blocks;
+  if (nwg >= (1u << 31)) return -1;
+  const int vec_out = (W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(corr) & 15) == 0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)S), dim3(kWave), lds, st, fmap1, fmap2, coords, offset, corr, B,
+                     S, H1, W1, H2, W2, blocks_x, blocks_y, xcd_map, vec_out);
+  return launch_status();
+}
+
+// Returns -1 when this kernel does not serve the arguments (the caller then uses the VALU tile kernel).
+int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  const bool aligned = ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
+  if (radius < 1 || radius > 3 || !aligned || S > 65535) return -1;
+  if (C != 32 && C != 64 && C != 128 && C != 256) return -1;
+  if ((size_t)H2 * W2 * C >= (1u << 31) || (size_t)H1 * W1 * C >= (1u << 31) || H2 > 32767 || W2 > 32767) return -1;
+#define LGU_MM_CASE(RV, KSV) \
+  if (radius == RV && C == 32 * KSV) return launch_mfma<RV, KSV>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, st);
+  LGU_MM_CASE(3, 4) LGU_MM_CASE(1, 4) LGU_MM_CASE(2, 4)
+  LGU_MM_CASE(3, 1) LGU_MM_CASE(1, 1) LGU_MM_CASE(2, 1)
+  LGU_MM_CASE(3, 2) LGU_MM_CASE(1, 2) LGU_MM_CASE(2, 2)
+  LGU_MM_CASE(3, 8) LGU_MM_CASE(1, 8) LGU_MM_CASE(2, 8)
+#undef LGU_MM_CASE
+  return -1;
+}
+
+}  // namespace lgu
+
+#ifdef LGU_MM_STAMPS
+// Diagnostic build only (tools/diag): never part of liblgu_corr.so.
+extern "C" {
+int lgu_mm_diag_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lgu::g_mm_stamps), &p, sizeof(p)); }
+int lgu_mm_diag_lowmem(const void* fmap1, const void* fmap2, const float* coords, float* offset, float* corr, int B, int S,
+                       int H1, int W1, int H2, int W2, int C, int radius, void* stream) {
+  return lgu::lowmem_mfma_dispatch(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2), coords, offset,
+                                   corr, B, S, H1, W1, H2, W2, C, radius, reinterpret_cast<hipStream_t>(stream));
+}
+}
+#endif

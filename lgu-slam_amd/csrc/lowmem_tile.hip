@@ -367,6 +367,21 @@ int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* co
   return tile_dispatch<float>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
 }
 
+// lowmem_mfma.hip
+int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st);
+
+// Half feature maps: the matrix-core kernel when it serves the shape, else the VALU tile kernel above.
+// LGU_LOWMEM_H16_VARIANT (debug/A-B only): 0 = matrix-core kernel, 1 = VALU tile kernel.
+static int h16_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                        int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  if (env_int("LGU_LOWMEM_H16_VARIANT", 0) == 0) {
+    const int rc = lowmem_mfma_dispatch(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
+    if (rc >= 0) return rc;
+  }
+  return tile_dispatch<_Float16>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
+}
+
 }  // namespace lgu
 
 extern "C" {
@@ -381,9 +396,8 @@ int lgu_lowmem_defsample_fwd_h16(const void* fmap1, const void* fmap2, const flo
   if (B < 0 || S < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
   if ((long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
   if (B == 0) return LGU_OK;
-  const int rc = lgu::tile_dispatch<_Float16>(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2),
-                                              coords, offset, corr, B, S, H1, W1, H2, W2, C, radius,
-                                              reinterpret_cast<hipStream_t>(stream));
+  const int rc = lgu::h16_dispatch(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2), coords,
+                                   offset, corr, B, S, H1, W1, H2, W2, C, radius, reinterpret_cast<hipStream_t>(stream));
   return rc < 0 ? LGU_E_UNSUPPORTED : rc;
 }
 
@@ -392,9 +406,8 @@ int lgu_altcorr_fwd_h16(const void* fmap1, const void* fmap2, const float* coord
   if (!fmap1 || !fmap2 || !coords || !corr) return LGU_E_BADARG;
   if (B < 0 || S < 1 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
   if (B == 0) return LGU_OK;
-  const int rc = lgu::tile_dispatch<_Float16>(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2),
-                                              coords, nullptr, corr, B, S, H1, W1, H2, W2, C, radius,
-                                              reinterpret_cast<hipStream_t>(stream));
+  const int rc = lgu::h16_dispatch(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2), coords,
+                                   nullptr, corr, B, S, H1, W1, H2, W2, C, radius, reinterpret_cast<hipStream_t>(stream));
   return rc < 0 ? LGU_E_UNSUPPORTED : rc;
 }
 

@@ -21,6 +21,9 @@ zero = torch.zeros_like(off0)
 for l in range(4):
     f2 = (torch.randn(B, H >> l, W >> l, C, device=dev) * 0.125).contiguous()
     cl = (base / 2 ** l).contiguous()
+    f1h, f2h = f1.half(), f2.half()
     for _ in range(3):
         ops.lowMem_defSample(f1, f2, cl, off0 if l < 2 else zero, 3)
+    for _ in range(5):
+        ops.lowMem_defSample_mixed(f1h, f2h, cl, off0 if l < 2 else zero, 3)
 torch.cuda.synchronize()
