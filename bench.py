@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--edges", type=int, default=20, help="edges per GPU (BASELINE config 2: 20)")
     ap.add_argument("--probe", action="store_true", help="also time the level-1 uncertainty probe in the step")
     ap.add_argument("--variant", type=int, default=0, help="LGU_DEFCORR_VARIANT (A/B only)")
+    ap.add_argument("--layout", choices=["tiled", "rowmajor"], default="tiled",
+                    help="storage of the pyramid the sampler reads: 'tiled' = the 4x8-tile slice layout CorrBlock keeps "
+                         "its pyramid in (production), 'rowmajor' = the reference operator's layout (drop-in operator path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -220,7 +223,12 @@ def main():
 
     # prepared launch: pointer tables built once, one ctypes call per step (the kernel is
     # ~60 us; per-call Python argument handling would otherwise bound the loop)
-    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe)
+    tiled = args.layout == "tiled"
+    level_hw = [(H1 >> l, W1 >> l) for l in range(L)]
+    if tiled:  # what CorrBlock.__init__ (ops.volume_pyramid(tiled=True)) leaves in HBM; conversion is setup, not timed
+        rowmajor_vols = vols
+        vols = [ops.volume_retile(v) for v in rowmajor_vols]
+    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe, tiled=tiled, level_hw=level_hw)
 
     def step():
         # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful
@@ -273,19 +281,22 @@ def main():
                     "ms": float(t.item()) * 1e3}
 
     if rank == 0:
-        A, U = algorithmic_bytes_per_unit(vols, coords, offs, R)
-        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,32>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32>", 5: "lgu::defcorr_gather_kernel<3,%s,12,2,16>",
-                 3: "lgu::defcorr_gather_kernel<3,%s,12,4,16>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
+        A, U = algorithmic_bytes_per_unit(rowmajor_vols if tiled else vols, coords, offs, R)
+        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
+                 5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
+                 3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
                  2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
+        kname = kname.replace("LAYOUT", "true" if tiled else "false")
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
         # because counters cannot be collected from inside the timed process; see profiles/.
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        tname = "traffic_r01_tiled.json" if tiled else "traffic_r01.json"
+        tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile) and E == 20 and not args.probe:
             t = json.load(open(tfile))
             if t.get("kernel") == kname:
-                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/traffic_r01.json"
+                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/" + tname
         kern_s = dev_ms * 1e-3 / args.steps  # average launch-to-launch device time of the step
         achieved = A * units / kern_s / 1e9
         res = {
@@ -296,7 +307,9 @@ def main():
             "config": {"workload": "BASELINE config 2: TartanAir-mono shape, 48x64 fmap, L=4, r=3, "
                                    "%d edges per GPU, fused 4-level deformable sample%s" % (E, " + level-1 probe" if args.probe else ""),
                        "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
-                       "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid"},
+                       "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid",
+                       "pyramid_layout": "4x8-tiled slices (CorrBlock's own storage; results bit-identical)" if tiled
+                                         else "row-major slices (reference operator layout)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": A * units,

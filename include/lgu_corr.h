@@ -95,6 +95,15 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
  *   mask = sigmoid(var), offsets[1] *= mask written back (the reference's stateful
  *   update) before level 1 is sampled. Requires L >= 2 and offsets[1] != NULL. */
 #define LGU_PYR_PROBE 1
+/* LGU_PYR_TILED: volumes[l] are in this library's tiled slice layout instead of the reference's row-major
+ *   H2 x W2 slices: every (edge,pixel) slice is stored as 4 x 8 element tiles (one 128-byte line each), tiles
+ *   row-major over the slice padded to multiples of (4, 8):
+ *     pos(y, x) = ((y/4) * ceil(W2/8) + x/8) * 32 + (y%4) * 8 + x%8,   slice pitch = ceil(H2/4)*ceil(W2/8)*32 floats.
+ *   HBM is fetched in whole 128-byte lines; a pixel's tap footprint touches ~40 % fewer lines in this layout.
+ *   H2[l], W2[l] stay the LOGICAL sizes.  Produced by lgu_volume_pyramid_tiled_f32 / lgu_volume_retile_f32.
+ *   Served for radius 3 (the production case); otherwise LGU_E_UNSUPPORTED.  Results are bit-identical to the
+ *   reference layout. */
+#define LGU_PYR_TILED 2
 int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords,
                                 float* const* offsets, float* out,
                                 int L, int E, int H1, int W1, const int* H2, const int* W2,
@@ -109,6 +118,15 @@ int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords
  * that fits LDS (<= 96 KiB); otherwise LGU_E_UNSUPPORTED and the caller composes the ops. */
 int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* volume, float* const* levels, int L,
                            int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* Same as lgu_volume_pyramid_f32 but every level is written in the tiled slice layout (LGU_PYR_TILED above).
+ * levels[0] may alias `volume` when H2 % 4 == 0 and W2 % 8 == 0 (the slice is converted in place). */
+int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const float* volume, float* const* levels,
+                                 int L, int E, int H1, int W1, int H2, int W2, int radius, void* stream);
+
+/* Layout conversion of `nslices` slices of H2 x W2 floats: to_tiled != 0: row-major -> tiled, else tiled -> row-major
+ * (padding elements of the tiled form are written as 0).  src and dst must not overlap. */
+int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream);
 
 /* ---- low-memory (on-the-fly correlation) path ---------------------------------- */
 

@@ -90,7 +90,15 @@ def _uncertainty_mask(probe):
 
 
 class CorrBlock:
-    """All-pairs correlation volume pyramid + deformable lookup (reference corr.py:52-152)."""
+    """All-pairs correlation volume pyramid + deformable lookup (reference corr.py:52-152).
+
+    In inference the pyramid this block owns is stored in the library's TILED slice layout (4 x 8 element
+    tiles = one 128-byte HBM line each, include/lgu_corr.h LGU_PYR_TILED): the fused builder writes it at no
+    extra cost and every lookup then touches ~40 % fewer HBM lines, with bit-identical results.
+    `CorrBlock.TILED_PYRAMID = False` keeps the reference's row-major slices (also used whenever gradients are
+    needed, for radius != 3 and for shapes the fused builder does not serve)."""
+
+    TILED_PYRAMID = True
 
     def __init__(self, ofsMap, ofs_residual, GA, fmap1, fmap2, num_levels=4, radius=3):
         self.num_levels = num_levels
@@ -108,13 +116,17 @@ class CorrBlock:
         self.t = feats.permute(0, 2, 3, 1).contiguous()
         needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(q.requires_grad for q in GA.parameters()))
         self.corr_pyramid = None
+        self._tiled = False
+        self._level_hw = [(h >> i, w >> i) for i in range(num_levels)]
         if not needs_grad and hasattr(GA, "gaussian_parameters"):
             # inference: Gaussian re-weighting, "/denominator + corr" and the 3 poolings in ONE
             # pass over the volume, level 0 in place (ops.volume_pyramid)
             mean_n, cov, det = GA.gaussian_parameters(self.t)
+            tiled = bool(CorrBlock.TILED_PYRAMID) and radius == 3
             try:
                 self.corr_pyramid = ops.volume_pyramid(mean_n.float().contiguous(), cov, volume.contiguous(), num_levels,
-                                                       GA.RADIUS, inplace=True)
+                                                       GA.RADIUS, inplace=True, tiled=tiled)
+                self._tiled = tiled
             except _lib.UnsupportedShape:
                 self.corr_pyramid = None
         if self.corr_pyramid is None:
@@ -165,19 +177,33 @@ class CorrBlock:
         key = tuple(t.data_ptr() for t in pyr) + tuple(o.data_ptr() if o is not None else 0 for o in offs)
         try:
             if getattr(self, "_plan_key", None) != key:
-                self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True)
+                self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True, tiled=self._tiled,
+                                                    level_hw=self._level_hw)
                 self._plan_key = key
             out = self._plan(coords)
         except _lib.UnsupportedShape:
             # shapes the fused probe does not serve (e.g. W2 % 4 != 0): separate probe ops
             self._plan_key = None
+            self._to_reference_layout()
+            pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
             probe, = ops.corr_index_forward(pyr[1], (coords / 2).contiguous(), 1)
             self.offset[1] = (self.offset[1] * _uncertainty_mask(probe)).contiguous()
             offs[1] = self.offset[1].view(E, ht, wd, rd, rd, 2)
             out = ops.defcorr_pyramid_forward(pyr, coords, offs, self.radius)
         return out.view(batch, num, -1, ht, wd), self.mean_n, self.theta
 
+    def _to_reference_layout(self):
+        """Row-major slices again (only needed to mix with a block built without the fused builder)."""
+        if self._tiled:
+            self.corr_pyramid = [ops.volume_retile(v.contiguous(), to_tiled=False, hw=self._level_hw[i])
+                                 for i, v in enumerate(self.corr_pyramid)]
+            self._tiled = False
+            self._plan_key = None
+
     def cat(self, other):
+        if self._tiled != other._tiled:
+            self._to_reference_layout()
+            other._to_reference_layout()
         for i in range(self.num_levels):
             self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
             self.offset[i] = torch.cat([self.offset[i], other.offset[i]], 0)

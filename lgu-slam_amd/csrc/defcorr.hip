@@ -51,7 +51,25 @@ struct PyrParams {
   int cbase;  // first channel this launch writes
   int lbase;  // pyramid level of vol[0] (coords are divided by 2^(lbase+l))
   int flags;
+  // slice geometry: floats per (edge,pixel) slice and, for the tiled layout, 4x8 tiles per tile row
+  int ssz[FASTL];
+  int tpr[FASTL];
 };
+
+// Position of target element (y, x) inside a slice.  Reference layout: row-major H2 x W2.
+// Tiled layout (LGU_PYR_TILED): 4 x 8 element tiles = one 128-byte line each, tiles row-major over the slice
+// padded to multiples of (4, 8).  HBM is fetched in whole 128-byte lines and a pixel's tap footprint is a
+// ~13 x 13 blob: in 4 x 8 tiles it touches 8.3 lines at level 0 instead of 14.9 as row segments.
+// Both forms are separable, addr = fy(y) + fx(x), so a neighbour is reached by adding a per-axis step.
+template <bool TILED>
+__device__ __forceinline__ int slice_pos(int y, int x, int W2, int tpr) {
+  if (!TILED) return y * W2 + x;
+  return (((y >> 2) * tpr + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+template <bool TILED>
+__device__ __forceinline__ int step_x(int x) { return TILED ? ((x & 7) == 7 ? 25 : 1) : 1; }
+template <bool TILED>
+__device__ __forceinline__ int step_y(int y, int W2, int tpr) { return TILED ? ((y & 3) == 3 ? tpr * 32 - 24 : 8) : W2; }
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -395,7 +413,7 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // the first result is used.  Far fewer instructions per pixel than the LDS-DMA kernel; the
 // price is L1/TA work per corner instead of per line.
 // GP = pixels per wave, TPX = pixels (along x) per workgroup: TPX / GP waves per workgroup
-template <int R, bool PROBE, int ZMASK, int GP, int TPX>
+template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED>
 __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   constexpr int LAT = 2 * R + 2;
@@ -477,7 +495,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       const int H2 = p.H2[1], W2 = p.W2[1];
       const int X = (int)floorf(cs[k][1].x) - 1 + (lane & 3), Y = (int)floorf(cs[k][1].y) - 1 + ((lane >> 2) & 3);
       if (lane < 16 && in_bounds(Y, X, H2, W2))
-        platv[k] = p.vol[1][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+        platv[k] = p.vol[1][(row_pix + px) * (size_t)p.ssz[1] + slice_pos<TILED>(Y, X, W2, p.tpr[1])];
     }
   }
 
@@ -496,8 +514,8 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     const int xc = clampi(x1, 0, W2 - 1), yc = clampi(y1, 0, H2 - 1);
     const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;
     gflag[k][l] = (valid ? 1 : 0) | (xin ? 2 : 0) | (yin ? 4 : 0);
-    const int dxo = xin ? 1 : 0, dyo = yin ? W2 : 0;
-    const float* s = p.vol[l] + (row_pix + (pv ? px : 0)) * ((size_t)H2 * W2) + (yc * W2 + xc);
+    const int dxo = xin ? step_x<TILED>(xc) : 0, dyo = yin ? step_y<TILED>(yc, W2, p.tpr[l]) : 0;
+    const float* s = p.vol[l] + (row_pix + (pv ? px : 0)) * (size_t)p.ssz[l] + slice_pos<TILED>(yc, xc, W2, p.tpr[l]);
     q[k][l][0] = s[0];
     q[k][l][1] = s[dxo];
     q[k][l][2] = s[dyo];
@@ -520,7 +538,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
         if (PIXOP == 1) {
           const int X = (int)floorf(cs[k][l].x) - R + lx, Y = (int)floorf(cs[k][l].y) - R + ly;
           if (pv && lat_on && in_bounds(Y, X, H2, W2))
-            latv[k][l] = p.vol[l][(row_pix + px) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+            latv[k][l] = p.vol[l][(row_pix + px) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
         } else if (k == 0) {
           const int pxl = xbase + w * GP + lpix;
           float cxl = cs[0][l].x, cyl = cs[0][l].y;
@@ -529,7 +547,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
             if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
           const int X = (int)floorf(cxl) - R + lx, Y = (int)floorf(cyl) - R + ly;
           if (pxl < p.W1 && lpix < GP && lat_on && in_bounds(Y, X, H2, W2))
-            latv[k][l] = p.vol[l][(row_pix + pxl) * ((size_t)H2 * W2) + (size_t)Y * W2 + X];
+            latv[k][l] = p.vol[l][(row_pix + pxl) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
         }
       } else if (!(PROBE && l == 1)) {
         issue_level(k, l);
@@ -670,16 +688,22 @@ static size_t pyr_lds_bytes(int L, int radius) {
   return sizeof(float) * ((size_t)NWAVE * POOL_FLOATS + (size_t)L * nt * OUT_PITCH);
 }
 
-// KIND 0: LDS-DMA staged kernel; KIND 1: register-gather kernel
+// KIND 0: LDS-DMA staged kernel; 1-3: register-gather kernel (4 px/wave; 2 px/wave with 16- / 32-pixel tiles);
+// 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles)
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
-  constexpr int tpx = KIND == 3 ? 32 : TP;
+  constexpr int tpx = (KIND == 3 || KIND == 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
-  auto kern = KIND == 0 ? defcorr_pyr_kernel<R, PROBE, ZMASK>
-              : KIND == 1 ? defcorr_gather_kernel<R, PROBE, ZMASK, 4, 16>
-              : KIND == 2 ? defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16> : defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32>;
-  const int nthreads = KIND == 3 ? 16 * kWave : KIND == 2 ? 8 * kWave : NWAVE * kWave;
+  // if constexpr: only the kernel of this KIND is instantiated
+  void (*kern)(const PyrParams);
+  if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
+  else if constexpr (KIND == 1) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 4, 16, false>;
+  else if constexpr (KIND == 2) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false>;
+  else if constexpr (KIND == 3) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, false>;
+  else if constexpr (KIND == 4) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
+  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
+  const int nthreads = (KIND == 3 || KIND == 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
   static bool attr_set = false;  // idempotent; racing setters write the same value
@@ -704,6 +728,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   for (int l = 0; l < L; l++)
     if (!volumes[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
   const bool probe = (flags & LGU_PYR_PROBE) != 0;
+  const bool tiled = (flags & LGU_PYR_TILED) != 0;
   if (probe && (L < 2 || offsets[1] == nullptr)) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -740,7 +765,9 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
 
     bool fast = (radius >= 1 && radius <= 3) && variant != 2 && aligned16(coords);
     for (int l = l0; l < l0 + nl; l++)
-      fast = fast && (W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
+      fast = fast && (tiled || W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
+    // the tiled layout is served by the production gather kernel at radius 3 only (what CorrBlock builds)
+    if (tiled && !(fast && radius == 3 && (variant == 0 || variant == 4 || variant == 5))) return LGU_E_UNSUPPORTED;
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {
@@ -749,6 +776,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
         p.off[l] = on ? offsets[l0 + l] : nullptr;
         p.H2[l] = on ? H2[l0 + l] : 1;
         p.W2[l] = on ? W2[l0 + l] : 4;
+        p.tpr[l] = (p.W2[l] + 7) >> 3;
+        p.ssz[l] = tiled ? ((p.H2[l] + 3) >> 2) * p.tpr[l] * 32 : p.H2[l] * p.W2[l];
       }
       p.coords = coords; p.out = out;
       p.L = nl; p.E = E; p.H1 = H1; p.W1 = W1;
@@ -762,9 +791,10 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       // workgroups) unless 16-pixel tiles waste fewer lanes on this W1
       const int slots16 = ((W1 + 15) / 16) * 16, slots32 = ((W1 + 31) / 32) * 32;
       const bool wide = variant == 4 || (variant != 5 && slots32 <= slots16);
-#define LGU_LAUNCH(PR, ZM)                                         \
-  (variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                          \
-                : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
+#define LGU_LAUNCH(PR, ZM)                                                                                     \
+  (tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
+         : variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                                                              \
+                        : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
       else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
 #undef LGU_LAUNCH

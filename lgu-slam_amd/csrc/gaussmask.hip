@@ -154,6 +154,14 @@ struct VolPyrParams {
   int H2, W2, L, r;
 };
 
+// TILED: every level is written in the tiled slice layout of include/lgu_corr.h (LGU_PYR_TILED): 4 x 8 element
+// tiles, one 128-byte line each.  The slice is complete in LDS before anything is written, so level 0 may
+// still be converted in place when its padded size equals H2*W2.
+__device__ __forceinline__ int tiled_pos(int y, int x, int tpr) {
+  return (((y >> 2) * tpr + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
+template <bool TILED>
 __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyrParams p) {
   extern __shared__ float4 vp_smem4[];
   float* const sm = reinterpret_cast<float*>(vp_smem4);
@@ -165,7 +173,9 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
   const int cx = (int)floorf(mx), cy = (int)floorf(my);
   const int xa = cx - p.r, xb = cx + p.r, ya = cy - p.r, yb = cy + p.r;
   const float4* vin = reinterpret_cast<const float4*>(p.vin + pix * (size_t)HW2);
-  float4* vout = reinterpret_cast<float4*>(p.out[0] + pix * (size_t)HW2);
+  const int tpr0 = (W2 + 7) >> 3;
+  const int ssz0 = TILED ? ((H2 + 3) >> 2) * tpr0 * 32 : HW2;
+  float4* vout = reinterpret_cast<float4*>(p.out[0] + pix * (size_t)ssz0);
   const int g_per_row = W2 >> 2;
   for (int gi = threadIdx.x; gi < (HW2 >> 2); gi += VP_THREADS) {
     const int row = gi / g_per_row;
@@ -179,7 +189,17 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
       if (x4 + 3 >= xa && x4 + 3 <= xb) v.w = (v.w * 3.0f * gauss_e(x4 + 3, row, mx, my, c1, c2)) / den + v.w;
     }
     reinterpret_cast<float4*>(sm)[gi] = v;
-    vout[gi] = v;
+    if (!TILED) vout[gi] = v;
+  }
+  if (TILED) {
+    __syncthreads();  // every read of vin is done: out[0] may alias it
+    for (int gi = threadIdx.x; gi < (ssz0 >> 2); gi += VP_THREADS) {
+      const int t = gi << 2, tile = t >> 5, ty = tile / tpr0, tx = tile - ty * tpr0;
+      const int y = ty * 4 + ((t & 31) >> 3), x = tx * 8 + (t & 7);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < H2 && x < W2) v = *reinterpret_cast<const float4*>(sm + y * W2 + x);  // W2 % 4 == 0
+      vout[gi] = v;
+    }
   }
   float* src = sm;
   int Hs = H2, Ws = W2;
@@ -187,17 +207,53 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
     __syncthreads();
     const int Hd = Hs >> 1, Wd = Ws >> 1;
     float* dst = src + Hs * Ws;
-    float* gout = p.out[l] + pix * (size_t)(Hd * Wd);
-    for (int idx = threadIdx.x; idx < Hd * Wd; idx += VP_THREADS) {
-      const int y = idx / Wd, x = idx - y * Wd;
-      const float* s = src + (2 * y) * Ws + 2 * x;
-      const float o = (((s[0] + s[1]) + s[Ws]) + s[Ws + 1]) / 4.0f;
-      dst[idx] = o;
-      gout[idx] = o;
+    if (!TILED) {
+      float* gout = p.out[l] + pix * (size_t)(Hd * Wd);
+      for (int idx = threadIdx.x; idx < Hd * Wd; idx += VP_THREADS) {
+        const int y = idx / Wd, x = idx - y * Wd;
+        const float* s = src + (2 * y) * Ws + 2 * x;
+        const float o = (((s[0] + s[1]) + s[Ws]) + s[Ws + 1]) / 4.0f;
+        dst[idx] = o;
+        gout[idx] = o;
+      }
+    } else {
+      const int tpr = (Wd + 7) >> 3, ssz = ((Hd + 3) >> 2) * tpr * 32;
+      float* gout = p.out[l] + pix * (size_t)ssz;
+      for (int t = threadIdx.x; t < ssz; t += VP_THREADS) {  // tiled order: coalesced stores
+        const int tile = t >> 5, ty = tile / tpr, tx = tile - ty * tpr;
+        const int y = ty * 4 + ((t & 31) >> 3), x = tx * 8 + (t & 7);
+        float o = 0.0f;
+        if (y < Hd && x < Wd) {
+          const float* s = src + (2 * y) * Ws + 2 * x;
+          o = (((s[0] + s[1]) + s[Ws]) + s[Ws + 1]) / 4.0f;
+          dst[y * Wd + x] = o;
+        }
+        gout[t] = o;
+      }
     }
     src = dst;
     Hs = Hd;
     Ws = Wd;
+  }
+}
+
+// Layout conversion of whole slices (setup / tests; not on the lookup path).
+__global__ __launch_bounds__(256) void volume_retile_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            size_t nslices, int H2, int W2, int to_tiled) {
+  const int tpr = (W2 + 7) >> 3;
+  const size_t ssz = (size_t)((H2 + 3) >> 2) * tpr * 32, rsz = (size_t)H2 * W2;
+  const size_t total = nslices * (to_tiled ? ssz : rsz);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    if (to_tiled) {
+      const size_t sl = idx / ssz;
+      const int t = (int)(idx - sl * ssz), tile = t >> 5, ty = tile / tpr, tx = tile - ty * tpr;
+      const int y = ty * 4 + ((t & 31) >> 3), x = tx * 8 + (t & 7);
+      dst[idx] = (y < H2 && x < W2) ? src[sl * rsz + (size_t)y * W2 + x] : 0.0f;
+    } else {
+      const size_t sl = idx / rsz;
+      const int r = (int)(idx - sl * rsz), y = r / W2, x = r - y * W2;
+      dst[idx] = src[sl * ssz + tiled_pos(y, x, tpr)];
+    }
   }
 }
 
@@ -246,8 +302,8 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
   return launch_status();
 }
 
-int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* volume, float* const* levels, int L,
-                           int E, int H1, int W1, int H2, int W2, int radius, void* stream) {
+static int volume_pyramid_host(const float* means, const float* covs, const float* volume, float* const* levels, int L,
+                               int E, int H1, int W1, int H2, int W2, int radius, bool tiled, void* stream) {
   using namespace lgu;
   if (!means || !covs || !volume || !levels || L < 1 || L > VP_MAXL) return LGU_E_BADARG;
   if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
@@ -255,6 +311,7 @@ int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* v
     if (!levels[l]) return LGU_E_BADARG;
   if (W2 % 4 != 0 || ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(levels[0])) & 15) != 0)
     return LGU_E_UNSUPPORTED;
+  if (tiled && levels[0] == volume && (H2 % 4 != 0 || W2 % 8 != 0)) return LGU_E_BADARG;  // padded slice cannot alias
   size_t floats = 0;
   for (int l = 0, h = H2, w = W2; l < L; l++, h >>= 1, w >>= 1) floats += (size_t)h * w;
   const size_t lds = floats * sizeof(float);
@@ -264,14 +321,35 @@ int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* v
   p.means = means; p.covs = covs; p.vin = volume;
   for (int l = 0; l < VP_MAXL; l++) p.out[l] = l < L ? levels[l] : nullptr;
   p.npix = (size_t)E * H1 * W1; p.H2 = H2; p.W2 = W2; p.L = L; p.r = radius;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(volume_pyramid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
-    attr_set = true;
+  auto kern = tiled ? volume_pyramid_kernel<true> : volume_pyramid_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[tiled]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[tiled] = true;
   }
-  hipLaunchKernelGGL(volume_pyramid_kernel, dim3((unsigned)p.npix), dim3(VP_THREADS), lds,
-                     reinterpret_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.npix), dim3(VP_THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
+  return launch_status();
+}
+
+int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int radius, void* stream) {
+  return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, false, stream);
+}
+
+int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const float* volume, float* const* levels,
+                                 int L, int E, int H1, int W1, int H2, int W2, int radius, void* stream) {
+  return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, true, stream);
+}
+
+int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream) {
+  using namespace lgu;
+  if (!src || !dst || nslices < 0 || H2 < 1 || W2 < 1) return LGU_E_BADARG;
+  if (nslices == 0) return LGU_OK;
+  const size_t per = to_tiled ? (size_t)((H2 + 3) >> 2) * ((W2 + 7) >> 3) * 32 : (size_t)H2 * W2;
+  const size_t want = ((size_t)nslices * per + 255) / 256;
+  const unsigned grid = (unsigned)(want < 65535u * 32 ? want : 65535u * 32);
+  hipLaunchKernelGGL(volume_retile_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst,
+                     (size_t)nslices, H2, W2, to_tiled);
   return launch_status();
 }
 

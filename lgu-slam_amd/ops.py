@@ -222,13 +222,58 @@ def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
     return [corr]
 
 
-def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None):
+PYR_PROBE, PYR_TILED = 1, 2  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)
+TILE_H, TILE_W = 4, 8        # tiled slice layout: 4 x 8 element tiles, one 128-byte line each
+
+
+def tiled_shape(E, H1, W1, H2, W2):
+    """Shape of a pyramid level in the tiled slice layout (include/lgu_corr.h, LGU_PYR_TILED)."""
+    return (E, H1, W1, -(-H2 // TILE_H), -(-W2 // TILE_W), TILE_H, TILE_W)
+
+
+def volume_retile(volume, to_tiled=True, hw=None):
+    """Layout conversion of a pyramid level.  to_tiled: (E,H1,W1,H2,W2) row-major slices -> tiled
+    (E,H1,W1,ceil(H2/4),ceil(W2/8),4,8) (padding zero-filled).  Otherwise the inverse; `hw` = the logical
+    (H2, W2) when the tiled form is padded.  Setup / test utility, not on the lookup path."""
+    _check(volume, "volume")
+    if to_tiled:
+        E, H1, W1, H2, W2 = volume.shape
+        out = torch.empty(tiled_shape(E, H1, W1, H2, W2), dtype=volume.dtype, device=volume.device)
+    else:
+        E, H1, W1, nty, ntx, th, tw = volume.shape
+        if (th, tw) != (TILE_H, TILE_W):
+            raise RuntimeError("volume_retile: not a tiled pyramid level")
+        H2, W2 = hw if hw is not None else (nty * TILE_H, ntx * TILE_W)
+        out = torch.empty((E, H1, W1, H2, W2), dtype=volume.dtype, device=volume.device)
+    n = E * H1 * W1
+    if n == 0:
+        return out
+    with torch.cuda.device(volume.device):
+        rc = _lib.load().lgu_volume_retile_f32(_ptr(volume), _ptr(out), n, H2, W2, 1 if to_tiled else 0, _stream(volume))
+    _lib.check(rc, "volume_retile")
+    return out
+
+
+def _level_dims(volumes, tiled, level_hw):
+    if not tiled:
+        return [v.shape[3] for v in volumes], [v.shape[4] for v in volumes]
+    if level_hw is None:
+        level_hw = [(v.shape[3] * TILE_H, v.shape[4] * TILE_W) for v in volumes]
+    for v, (h, w) in zip(volumes, level_hw):
+        if v.dim() != 7 or tuple(v.shape[3:]) != (-(-h // TILE_H), -(-w // TILE_W), TILE_H, TILE_W):
+            raise RuntimeError("tiled pyramid level must be (E,H1,W1,ceil(H2/4),ceil(W2/8),4,8)")
+    return [h for h, _ in level_hw], [w for _, w in level_hw]
+
+
+def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None, tiled=False, level_hw=None):
     """Fused CorrBlock.__call__ body (reference droid_slam/modules/corr.py:88-109): all
     pyramid levels in ONE launch, written straight into the concatenated tensor.
 
     volumes: list of L tensors (E,H1,W1,H2l,W2l); coords (E,2,H1,W1) in level-0 units
     (each level samples at coords / 2^l); offsets: list of L tensors (E,H1,W1,rd,rd,2)
     or None for a structurally-zero level.  Offsets are modified in place (centre zeroing).
+    tiled=True: volumes are in the tiled slice layout (volume_retile / volume_pyramid(tiled=True));
+    level_hw = their logical (H2, W2) when padded.  Same results, fewer HBM lines touched.
     Returns (E, L*rd*rd, H1, W1).
     """
     L = len(volumes)
@@ -241,6 +286,7 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
             _check(offsets[l], "offset[%d]" % l)
     E, H1, W1 = volumes[0].shape[:3]
     rd = 2 * radius + 1
+    hs, ws = _level_dims(volumes, tiled, level_hw)
     if out is None:
         out = torch.empty((E, L * rd * rd, H1, W1), dtype=torch.float32, device=coords.device)
     else:
@@ -249,31 +295,40 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
         return out
     vp = (_vp * L)(*[v.data_ptr() for v in volumes])
     op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
-    h2 = (ctypes.c_int * L)(*[v.shape[3] for v in volumes])
-    w2 = (ctypes.c_int * L)(*[v.shape[4] for v in volumes])
+    h2 = (ctypes.c_int * L)(*hs)
+    w2 = (ctypes.c_int * L)(*ws)
+    flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0)
     with torch.cuda.device(coords.device):
         rc = _lib.load().lgu_defcorr_pyramid_fwd_f32(vp, _ptr(coords), op, _ptr(out), L, E, H1, W1, h2, w2, radius,
-                                                     1 if probe else 0, _stream(coords))
+                                                     flags, _stream(coords))
     _lib.check(rc, "defcorr_pyramid_forward")
     return out
 
 
-def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False):
+def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, tiled=False):
     """Fused volume post-processing of CorrBlock.__init__ (reference gaussianMask_cuda.py:84-86
     + corr.py:79-86): level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(det)) +
     volume, levels 1.. by 2x2 average pooling of the target dims — one pass over the volume.
-    Returns the list of pyramid levels; with inplace=True level 0 reuses `volume`'s storage."""
+    Returns the list of pyramid levels; with inplace=True level 0 reuses `volume`'s storage.
+    tiled=True: the levels are written in the tiled slice layout (tiled_shape); same values."""
     _check(volume, "volume", means, "means", covs, "covs")
     E, H1, W1, H2, W2 = volume.shape
-    levels = [volume if inplace else torch.empty_like(volume)]
-    for l in range(1, num_levels):
-        levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+    if tiled:
+        alias = inplace and H2 % TILE_H == 0 and W2 % TILE_W == 0
+        levels = [volume.view(tiled_shape(E, H1, W1, H2, W2)) if alias
+                  else torch.empty(tiled_shape(E, H1, W1, H2, W2), dtype=volume.dtype, device=volume.device)]
+        for l in range(1, num_levels):
+            levels.append(torch.empty(tiled_shape(E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+    else:
+        levels = [volume if inplace else torch.empty_like(volume)]
+        for l in range(1, num_levels):
+            levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
     if E == 0:
         return levels
     lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
+    fn = _lib.load().lgu_volume_pyramid_tiled_f32 if tiled else _lib.load().lgu_volume_pyramid_f32
     with torch.cuda.device(volume.device):
-        rc = _lib.load().lgu_volume_pyramid_f32(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2,
-                                                W2, radius, _stream(volume))
+        rc = fn(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2, W2, radius, _stream(volume))
     _lib.check(rc, "volume_pyramid")
     return levels
 
@@ -285,7 +340,7 @@ class DefcorrPyramidPlan:
     every update) and by bench.py so the step is not bound by Python argument handling.
     """
 
-    def __init__(self, volumes, offsets, radius, probe=False):
+    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None):
         L = len(volumes)
         if len(offsets) != L:
             raise RuntimeError("DefcorrPyramidPlan: need one offset entry (tensor or None) per level")
@@ -296,14 +351,15 @@ class DefcorrPyramidPlan:
                 named += [offsets[l], "offset[%d]" % l]
         _check(*named)
         self._keep = (list(volumes), list(offsets))  # keep the buffers alive
-        self.L, self.radius, self.flags = L, radius, (1 if probe else 0)
+        self.L, self.radius, self.flags = L, radius, (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0)
         self.E, self.H1, self.W1 = volumes[0].shape[:3]
         self.device = volumes[0].device
         self.channels = L * (2 * radius + 1) ** 2
         self._vp = (_vp * L)(*[v.data_ptr() for v in volumes])
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
-        self._h2 = (ctypes.c_int * L)(*[v.shape[3] for v in volumes])
-        self._w2 = (ctypes.c_int * L)(*[v.shape[4] for v in volumes])
+        hs, ws = _level_dims(volumes, tiled, level_hw)
+        self._h2 = (ctypes.c_int * L)(*hs)
+        self._w2 = (ctypes.c_int * L)(*ws)
         self._fn = _lib.load().lgu_defcorr_pyramid_fwd_f32
 
     def __call__(self, coords, out=None):

@@ -632,9 +632,12 @@ def test_full_size_properties(lgu):
     assert torch.equal(gen, out)
 
 
-def test_corrblock_matches_reference_shaped_composition(lgu, oracle):
+@pytest.mark.parametrize("tiled", [True, False])
+def test_corrblock_matches_reference_shaped_composition(lgu, oracle, tiled, monkeypatch):
     """Host glue: CorrBlock.__call__ (fused launch) == probe + mask + 4 per-level oracle
-    calls + cat, including the persistent offset[1] *= mask state across two calls."""
+    calls + cat, including the persistent offset[1] *= mask state across two calls.  Run over both
+    storage layouts of the block's own pyramid (tiled = production, row-major = reference)."""
+    monkeypatch.setattr(lgu.CorrBlock, "TILED_PYRAMID", tiled)
     torch.manual_seed(3)
     E, h, w = 2, 48, 64
     dev_ = "cuda"
@@ -647,13 +650,16 @@ def test_corrblock_matches_reference_shaped_composition(lgu, oracle):
     ys, xs = torch.meshgrid(torch.arange(h, device=dev_).float(), torch.arange(w, device=dev_).float(), indexing="ij")
     with torch.no_grad():
         blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
-        pyr = [host(v) for v in blk.corr_pyramid]
+        assert blk._tiled == tiled
+        rowmajor = [lgu.ops.volume_retile(v.contiguous(), to_tiled=False, hw=blk._level_hw[i]) if tiled else v
+                    for i, v in enumerate(blk.corr_pyramid)]
+        pyr = [host(v) for v in rowmajor]
         # fused __init__ (volume_pyramid) vs the reference-shaped composition GA.forward + avg_pool2d
         vol = lgu.CorrBlock.corr(f1, f2).view(E, h, w, h, w).float()
         ref0, _, _ = GA(blk.t, vol)
-        assert (blk.corr_pyramid[0] - ref0).abs().max() <= 1e-6
+        assert (rowmajor[0] - ref0).abs().max() <= 1e-6
         ref1 = torch.nn.functional.avg_pool2d(ref0.reshape(E * h * w, 1, h, w), 2, stride=2).view(E, h, w, h // 2, w // 2)
-        assert (blk.corr_pyramid[1] - ref1).abs().max() <= 1e-6
+        assert (rowmajor[1] - ref1).abs().max() <= 1e-6
         offs = [host(o.contiguous()).reshape(E, h, w, 7, 7, 2).copy() for o in blk.offset]
         for it in range(2):
             coords1 = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device=dev_))
@@ -666,3 +672,111 @@ def test_corrblock_matches_reference_shaped_composition(lgu, oracle):
             offs[1] = (offs[1] * mask).astype(np.float32)
             want = oracle.defcorr_pyramid_forward(pyr, c, [offs[0], offs[1], None, None], 3)
             assert np.abs(host(got)[0] - want).max() <= 2e-5, "call %d" % it
+
+
+TILED_CASES = {
+    # name: (seed, E, H1, W1, L, sigma, off_scale, dense)
+    "cfg2_shape": (31, 2, 48, 64, 4, 3.0, 4.0, False),          # level 3 is 6x8: padded to 8x8 in the tiled form
+    "border_stress": (32, 2, 24, 32, 3, 20.0, 4.0, False),
+    "dense_offsets": (33, 1, 24, 32, 3, 3.0, 4.0, True),
+    "ragged": (34, 2, 30, 40, 2, 3.0, 4.0, False),              # 30x40 and 15x20 slices: both dims padded
+    "huge_offsets": (35, 1, 48, 64, 2, 3.0, 14.0, True),
+    "w2_not_mult4": (36, 1, 20, 24, 3, 3.0, 4.0, False),        # level 2 is 5x6: row-major needs the generic kernel, tiled does not
+}
+
+
+@pytest.mark.parametrize("variant", [0, 4, 5])
+@pytest.mark.parametrize("probe", [False, True])
+@pytest.mark.parametrize("name", list(TILED_CASES))
+def test_tiled_pyramid_layout_is_bitwise_the_reference_layout(lgu, oracle, name, probe, variant):
+    """LGU_PYR_TILED: the same lookup over the 4x8-tiled slice layout.  volume_retile round-trips exactly,
+    the tiled lookup equals the row-major lookup BIT FOR BIT (same loads, same arithmetic, other addresses),
+    offsets get the same side effects, and the result matches the oracle."""
+    seed, E, H1, W1, L, sigma, osc, dense = TILED_CASES[name]
+    case = inputs.pyramid_case(seed, E, H1, W1, L, 3, sigma, osc, dense)
+    vols = [dev(v) for v in case["volumes"]]
+    hw = [tuple(v.shape[3:]) for v in vols]
+    tv = [lgu.ops.volume_retile(v) for v in vols]
+    for v, t, (h2, w2) in zip(vols, tv, hw):
+        assert tuple(t.shape) == lgu.ops.tiled_shape(E, H1, W1, h2, w2)
+        assert torch.equal(lgu.ops.volume_retile(t, to_tiled=False, hw=(h2, w2)), v)
+    coords = dev(case["coords"])
+    offs_a = [dev(o) if o is not None else None for o in case["offsets"]]
+    offs_b = [dev(o) if o is not None else None for o in case["offsets"]]
+    set_variant(variant)
+    got = lgu.ops.defcorr_pyramid_forward(tv, coords, offs_a, 3, probe=probe, tiled=True, level_hw=hw)
+    set_variant(2 if (name == "w2_not_mult4" and not probe) else variant)
+    if name == "w2_not_mult4" and probe:
+        want_np = oracle.defcorr_pyramid_forward(case["volumes"], case["coords"],
+                                                 [o.copy() if o is not None else None for o in case["offsets"]], 3, probe=True)
+        assert np.abs(host(got) - want_np).max() <= 1e-5
+        return
+    want = lgu.ops.defcorr_pyramid_forward(vols, coords, offs_b, 3, probe=probe)
+    assert torch.equal(got, want)
+    for a, b in zip(offs_a, offs_b):
+        assert a is None or torch.equal(a, b)
+    ref_offs = [o.copy() if o is not None else None for o in case["offsets"]]
+    want_np = oracle.defcorr_pyramid_forward(case["volumes"], case["coords"], ref_offs, 3, probe=probe)
+    assert np.abs(host(got) - want_np).max() <= (1e-5 if probe else 1e-6)
+
+
+def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
+    v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
+    tv = [lgu.ops.volume_retile(x) for x in v]
+    c = torch.zeros(1, 2, 8, 16, device="cuda")
+    with pytest.raises(lgu._lib.UnsupportedShape):   # radius 1: only the production radius is tiled
+        lgu.ops.defcorr_pyramid_forward(tv, c, [None, None], 1, tiled=True)
+    with pytest.raises(RuntimeError):                # row-major tensors passed as tiled
+        lgu.ops.defcorr_pyramid_forward(v, c, [None, None], 3, tiled=True)
+
+
+@pytest.mark.parametrize("shape,L", [((2, 12, 16, 12, 16), 3), ((1, 48, 64, 48, 64), 4), ((2, 6, 8, 20, 24), 2)])
+def test_volume_pyramid_fused_tiled(lgu, shape, L):
+    """lgu_volume_pyramid_tiled_f32 == retile(lgu_volume_pyramid_f32) bit for bit, also converting level 0 in place."""
+    E, H1, W1, H2, W2 = shape
+    torch.manual_seed(40 + H2)
+    v = torch.randn(E, H1, W1, H2, W2, device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H1, device="cuda").float(), torch.arange(W1, device="cuda").float(), indexing="ij")
+    means = (torch.stack([xs * W2 / W1, ys * H2 / H1], -1)[None] + 2 * torch.randn(E, H1, W1, 2, device="cuda")).contiguous()
+    covs = (torch.rand(E, H1, W1, 2, device="cuda") * 5 + 0.05).contiguous()
+    ref = lgu.ops.volume_pyramid(means, covs, v, L, 4)
+    got = lgu.ops.volume_pyramid(means, covs, v, L, 4, tiled=True)
+    for l in range(L):
+        assert torch.equal(got[l], lgu.ops.volume_retile(ref[l]))
+    if H2 % 4 == 0 and W2 % 8 == 0:
+        v2 = v.clone()
+        inp = lgu.ops.volume_pyramid(means, covs, v2, L, 4, inplace=True, tiled=True)
+        assert inp[0].data_ptr() == v2.data_ptr() and torch.equal(inp[0], got[0]) and torch.equal(inp[-1], got[-1])
+
+
+def test_corrblock_layouts_agree_and_cat(lgu, monkeypatch):
+    """CorrBlock built with the tiled pyramid == built with the row-major pyramid (to 2e-5: the offset convs and
+    the volume matmul of two constructions are not bitwise reproducible; the lookup itself is, see
+    test_tiled_pyramid_layout_is_bitwise_the_reference_layout), and cat / __getitem__ keep working on the
+    tiled form (they only touch the edge dimension)."""
+    torch.manual_seed(8)
+    E, h, w = 3, 24, 32
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    GA = lgu.GaussianMask(h, w).cuda()
+    f1 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda").float(), torch.arange(w, device="cuda").float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device="cuda")
+    outs = {}
+    with torch.no_grad():
+        for tiled in (True, False):
+            monkeypatch.setattr(lgu.CorrBlock, "TILED_PYRAMID", tiled)
+            blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+            assert blk._tiled == tiled
+            outs[tiled] = [blk(coords)[0].clone(), blk(coords)[0].clone()]   # second call: persistent mask state
+        assert float((outs[True][0] - outs[False][0]).abs().max()) <= 2e-5
+        assert float((outs[True][1] - outs[False][1]).abs().max()) <= 2e-5
+        monkeypatch.setattr(lgu.CorrBlock, "TILED_PYRAMID", True)
+        a = lgu.CorrBlock(ofsMap, ofsRes, GA, f1[:, :2], f2[:, :2])
+        b = lgu.CorrBlock(ofsMap, ofsRes, GA, f1[:, 2:], f2[:, 2:])
+        whole = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        got = a.cat(b)(coords)[0]
+        assert a._tiled and float((got - whole(coords)[0]).abs().max()) <= 2e-5
+        sub = whole[torch.tensor([0, 2], device="cuda")]
+        assert sub(coords[:, [0, 2]])[0].shape == (1, 2, 196, h, w)
