@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 output of tools/gpu_full_run.sh (gpurun_out/prof_{trace,fetch,write}) into the
-small tracked summaries under profiles/: kernel-stats CSV (top rows), PMC traffic JSON (with the gfx950
-FETCH_SIZE correction) and one combined JSON with the bench lines and the reference comparison."""
+"""Turns the raw rocprofv3 output of tools/gpu_full_run.sh (gpurun_out/prof_{trace,fetch,write}[_rm], prof_lm) into the
+small tracked summaries under profiles/: kernel-stats CSVs (top rows), PMC traffic JSONs (with the gfx950
+FETCH_SIZE correction) for both pyramid layouts, the low-memory kernel trace, and one combined JSON with the bench
+lines and the reference comparison.  Usage: collect_profiles.py [tag]   (default r01)"""
+import collections
 import csv
 import glob
 import json
@@ -23,45 +25,75 @@ def rows(name, suffix):
     return list(csv.DictReader(open(newest(name, suffix))))
 
 
-ks = rows("prof_trace", "kernel_stats")
-kern = [r for r in ks if "defcorr_gather" in r["Name"]][0]
-kname = kern["Name"].replace("void ", "").split("(")[0].replace(", ", ",")
+def layout_summary(sfx, layout):
+    ks = rows("prof_trace" + sfx, "kernel_stats")
+    kern = [r for r in ks if "defcorr_gather" in r["Name"]][0]
+    kname = kern["Name"].replace("void ", "").split("(")[0].replace(", ", ",")
+
+    def mean(name, ctr):
+        v = [(float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+             for r in rows(name, "counter_collection") if "defcorr_gather" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        return sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)
+
+    f, fd, fn = mean("prof_fetch" + sfx, "FETCH_SIZE")
+    w, wd, wn = mean("prof_write" + sfx, "WRITE_SIZE")
+    cmd = "python3 bench.py --steps %d --warmup %d --no-cpu --layout " + layout
+    traffic = {
+        "kernel": kname,
+        "pyramid_layout": layout,
+        "workload": "BASELINE config 2, E=20 (61440 units per launch)",
+        "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd % (20, 2),
+                     "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- " + cmd % (20, 2),
+                     "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd % (200, 20)],
+        "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w, "dispatches_fetch": fn, "dispatches_write": wn,
+        "fetch_correction": 2.0,
+        "fetch_correction_basis": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md HBM section); calibrated on known "
+                                  "byte counts: tools/calib_fetch.py (59.47 MB known read -> 29500 KiB raw = factor 1.97; torch copy of 755 MB "
+                                  "-> 368680 KiB raw = factor 2.00; WRITE_SIZE exact) and against a host-side count of the distinct 128-B lines "
+                                  "the taps touch (row-major: 4819 B/unit modelled vs 2x raw measured)",
+        "hbm_read_bytes_per_launch": f * 1024 * 2, "hbm_write_bytes_per_launch": w * 1024,
+        "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
+        "hbm_bytes_per_unit": (f * 1024 * 2 + w * 1024) / 61440.0,
+        "kernel_avg_ns_kernel_trace": float(kern["AverageNs"]), "kernel_calls_kernel_trace": int(kern["Calls"]),
+        "kernel_avg_ns_under_pmc": (fd + wd) / 2,
+    }
+    raw = list(csv.reader(open(newest("prof_trace" + sfx, "kernel_stats"))))
+    return kern, traffic, [raw[0]] + [[r[0][:120]] + r[1:] for r in raw[1:13]]
 
 
-def mean(name, ctr):
-    v = [(float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-         for r in rows(name, "counter_collection") if "defcorr_gather" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
-    return sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)
+kern_t, traffic_t, stats_t = layout_summary("", "tiled")
+kern_r, traffic_r, stats_r = layout_summary("_rm", "rowmajor")
+json.dump(traffic_t, open(os.path.join(P, "traffic_%s_tiled.json" % tag), "w"), indent=1)
+json.dump(traffic_r, open(os.path.join(P, "traffic_%s.json" % tag), "w"), indent=1)
+csv.writer(open(os.path.join(P, "%s_kernel_stats.csv" % tag), "w")).writerows(stats_t)
+csv.writer(open(os.path.join(P, "%s_kernel_stats_rowmajor.csv" % tag), "w")).writerows(stats_r)
 
+# low-memory path: per-launch kernel durations, in launch order (tools/prof_lowmem.py: levels 0..3, f32 x3 then half x5)
+per = collections.OrderedDict()
+for r in csv.DictReader(open(newest("prof_lm", "kernel_trace"))):
+    n = r["Kernel_Name"]
+    if "lowmem" in n:
+        per.setdefault(n.split("(")[0].replace("void ", ""), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+lowmem = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/prof_lowmem.py",
+          "workload": "BASELINE config 4 shapes: B=16 edges, 60x80x128 feature maps, levels 0..3, r=3",
+          "kernel_us_per_launch_in_order": per,
+          "level_totals_us": {n: [round(sum(v[i * (len(v) // 4):(i + 1) * (len(v) // 4)]) / (len(v) // 4), 2) for i in range(4)] for n, v in per.items()}}
+lowmem["four_level_total_us"] = {n: round(sum(v), 1) for n, v in lowmem["level_totals_us"].items()}
+lowmem["Mpix_edges_per_s"] = {n: round(16 * 60 * 80 / t, 1) for n, t in lowmem["four_level_total_us"].items()}
+json.dump(lowmem, open(os.path.join(P, "%s_lowmem_kernels.json" % tag), "w"), indent=1)
 
-f, fd, fn = mean("prof_fetch", "FETCH_SIZE")
-w, wd, wn = mean("prof_write", "WRITE_SIZE")
-traffic = {
-    "kernel": kname,
-    "workload": "BASELINE config 2, E=20 (61440 units per launch)",
-    "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu",
-                 "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 20 --warmup 2 --no-cpu",
-                 "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu"],
-    "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w, "dispatches_fetch": fn, "dispatches_write": wn,
-    "fetch_correction": 2.0,
-    "fetch_correction_basis": "gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md HBM section); calibrated on known "
-                              "byte counts: tools/calib_fetch.py (59.47 MB known read -> 29500 KiB raw = factor 1.97; torch copy of 755 MB "
-                              "-> 368680 KiB raw = factor 2.00; WRITE_SIZE exact) and against a host-side count of the distinct 128-B lines "
-                              "the taps touch (4819 B/unit modelled vs 2x raw measured)",
-    "hbm_read_bytes_per_launch": f * 1024 * 2, "hbm_write_bytes_per_launch": w * 1024,
-    "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
-    "kernel_avg_ns_kernel_trace": float(kern["AverageNs"]), "kernel_calls_kernel_trace": int(kern["Calls"]),
-    "kernel_avg_ns_under_pmc": (fd + wd) / 2,
-}
-json.dump(traffic, open(os.path.join(P, "traffic_%s.json" % tag), "w"), indent=1)
-raw = list(csv.reader(open(newest("prof_trace", "kernel_stats"))))
-csv.writer(open(os.path.join(P, "%s_kernel_stats.csv" % tag), "w")).writerows([raw[0]] + [[r[0][:120]] + r[1:] for r in raw[1:13]])
 b = json.load(open(os.path.join(G, "bench.json")))
+br = json.load(open(os.path.join(G, "bench_rowmajor.json")))
 bp = json.load(open(os.path.join(G, "bench_probe.json")))
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
-json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py, bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic, "
+keep = ("value", "ms_per_step", "roofline", "config")
+json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py (tiled pyramid), bench.py --layout rowmajor, "
+                   "bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic for both layouts, low-memory kernel trace, "
                    "comparison with the reference kernels (oracle/_ref) on the same device",
-           "bench": b, "bench_probe": {k: bp[k] for k in ("value", "ms_per_step", "roofline")},
-           "kernel_stats_defcorr": {k: kern[k] for k in kern}, "traffic": traffic, "compare_ref": cmp_},
+           "bench": b, "bench_rowmajor": {k: br[k] for k in keep}, "bench_probe": {k: bp[k] for k in keep},
+           "kernel_stats_defcorr_tiled": dict(kern_t), "kernel_stats_defcorr_rowmajor": dict(kern_r),
+           "traffic_tiled": traffic_t, "traffic_rowmajor": traffic_r, "lowmem_kernels": lowmem, "compare_ref": cmp_},
           open(os.path.join(P, "%s_final.json" % tag), "w"), indent=1)
-print(kname, kern["AverageNs"], traffic["hbm_bytes_per_launch"])
+print(traffic_t["kernel"], kern_t["AverageNs"], traffic_t["hbm_bytes_per_unit"])
+print(traffic_r["kernel"], kern_r["AverageNs"], traffic_r["hbm_bytes_per_unit"])
+print(lowmem["four_level_total_us"])
