@@ -18,19 +18,21 @@ dev = torch.device("cuda:0")
 E, H1, W1, L, R = 20, 48, 64, 4, 3
 vols, coords, offs = bench.make_inputs(E, H1, W1, L, R, 1234, dev)
 out = torch.empty(E, 196, H1, W1, device=dev)
-configs = [dict(variant=v, nt=0, probe=pr) for v in (0, 5, 3, 1) for pr in (False, True)]
+tvols = [ops.volume_retile(v) for v in vols]
+hw = [(H1 >> l, W1 >> l) for l in range(L)]
+configs = [dict(variant=v, tiled=t, probe=pr) for t in (True, False) for v in ((0, 5) if t else (0, 5, 3, 1)) for pr in (False, True)]
 times = {i: [] for i in range(len(configs))}
 
 
 def run(c, iters):
     os.environ["LGU_DEFCORR_VARIANT"] = str(c["variant"])
-    os.environ["LGU_DEFCORR_NT"] = str(c["nt"])
+    v = tvols if c["tiled"] else vols
     for _ in range(3):
-        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=c["probe"], out=out)
+        ops.defcorr_pyramid_forward(v, coords, offs, R, probe=c["probe"], out=out, tiled=c["tiled"], level_hw=hw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.defcorr_pyramid_forward(vols, coords, offs, R, probe=c["probe"], out=out)
+        ops.defcorr_pyramid_forward(v, coords, offs, R, probe=c["probe"], out=out, tiled=c["tiled"], level_hw=hw)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3  # us
