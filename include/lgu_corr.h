@@ -157,10 +157,13 @@ int lgu_altcorr_bwd_f32(const float* fmap1, const float* fmap2, const float* coo
 
 /* Mixed-precision forms of the two low-memory forward operators: feature maps in IEEE half
  * (as droid_slam/depth_video.py stores them), everything else — coords, offsets, products,
- * sums, output — fp32.  Bit-identical to calling the _f32 entry on fmap.float(): the reference
- * call sites (droid_slam/modules/corr.py:202,209) do exactly that conversion first; these entries
- * skip the conversion passes and stage half the bytes.  Same shapes/side effects as the _f32
- * forms; require C % 16 == 0 and radius in 1..3, otherwise LGU_E_UNSUPPORTED. */
+ * sums, output — fp32.  The reference call sites (droid_slam/modules/corr.py:202,209) convert with
+ * .float() and run the fp32 operator; these entries skip the conversion passes and, for
+ * C in {32, 64, 128, 256}, run the channel contraction on the matrix cores
+ * (v_mfma_f32_16x16x32_f16: half products are exact in fp32, accumulation is fp32), so the result
+ * equals the _f32 entry on fmap.float() up to fp32 summation order (<= 1e-5; measured 2.4e-7).
+ * Other C (multiples of 16) take a VALU kernel that is bit-identical to the _f32 entry.
+ * Same shapes/side effects as the _f32 forms; radius in 1..3, otherwise LGU_E_UNSUPPORTED. */
 int lgu_lowmem_defsample_fwd_h16(const void* fmap1_half, const void* fmap2_half, const float* coords,
                                  float* offset, float* corr,
                                  int B, int S, int H1, int W1, int H2, int W2, int C, int NO,
