@@ -172,6 +172,20 @@ int lgu_altcorr_fwd_h16(const void* fmap1_half, const void* fmap2_half, const fl
                         int B, int S, int H1, int W1, int H2, int W2, int C,
                         int radius, void* stream);
 
+/* The per-level loop of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:192-213) in ONE launch, for
+ * half feature maps: for l in 0..L-1   out[:, :, l*rd*rd:(l+1)*rd*rd] =
+ *     lowMem_defSample(fmap1.float(), fmap2[l].float(), coords / 2^l, offsets[l], radius)
+ * written straight into the concatenated tensor out (B,S,L*rd*rd,H1,W1) (what corr.py:211-213 builds for S == 1).
+ * fmap2[l] (B,H2[l],W2[l],C) half; coords (B,S,H1,W1,2) in level-0 units; offsets[l] (NO,H1,W1,rd,rd,2) IN/OUT with the
+ * reference's offset[b*s] indexing, or NULL = zero offsets for that level.  `fmap2`, `offsets`, `H2`, `W2` are HOST
+ * arrays of length L <= 4.  The level-1 uncertainty probe of corr.py:201-206 stays a separate call
+ * (lgu_altcorr_fwd_h16) whose mask the caller folds into offsets[1] first.  Requires C in {32,64,128,256} and
+ * radius in 1..3, otherwise LGU_E_UNSUPPORTED (compose the per-level entries instead). */
+int lgu_lowmem_pyramid_fwd_h16(const void* fmap1_half, const void* const* fmap2_half, const float* coords,
+                               float* const* offsets, float* out,
+                               int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,12 +254,31 @@ class AltCorrBlock:
         f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
         # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
         feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float()
-        self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+        self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
 
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
         # operators accumulate in fp32 and equal the reference's `.float()` call sites bit for bit.
         mixed = f1.dtype == torch.float16
         f1 = f1.contiguous() if mixed else f1.float().contiguous()
+        if mixed and S == 1 and B == 1 and self.num_levels >= 2:
+            # half features, one sample per pixel (the SLAM system's case): the level-1 probe, then ALL levels in
+            # one launch written straight into the concatenated tensor (ops.LowmemPyramidPlan); levels whose
+            # offsets are zero by construction read no offset tensor at all
+            try:
+                f2s = [self.pyramid[i][:, jj].reshape((B * N,) + self.pyramid[i].shape[2:]).contiguous()
+                       for i in range(self.num_levels)]
+                c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
+                probe, = ops.altcorr_forward_mixed(f1, f2s[1], (c0 / 2).contiguous(), 1)
+                probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
+                mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
+                self.offset[1] = self.offset[1] * mask
+                offs = [None if zero_level[i] else self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
+                        for i in range(self.num_levels)]
+                fused = ops.lowmem_pyramid_forward_mixed(f1, f2s, c0, offs, self.radius)  # (E,1,L*rd*rd,H,W)
+                return fused.view(B, N, -1, H, W).unsqueeze(-1)
+            except _lib.UnsupportedShape:
+                # channel counts / radii the matrix-core kernel does not serve: per-level operators below
+                self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
         out = []
         for i in range(self.num_levels):
             f2 = self.pyramid[i][:, jj]

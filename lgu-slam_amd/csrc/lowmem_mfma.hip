@@ -84,14 +84,27 @@ __device__ unsigned long long* g_mm_stamps;  // [wave][8]
 #define MM_STAMP(i)
 #endif
 
+constexpr int MM_MAXL = 4;  // pyramid levels one launch can serve
+
+// Launch parameters.  L == 1: one operator call (lowMem_defSample / altcorr_forward).  L > 1: the per-level loop of
+// AltCorrBlock.corr_fn (reference corr.py:192-213) in ONE launch: work items are (level, edge, block) with level 0
+// (the largest windows) first, level l samples fmap2[l] at coords / 2^l with offset[l] and writes channels
+// l*NT .. (l+1)*NT - 1 of the concatenated output.
+struct MmParams {
+  const _Float16* fmap1;
+  const _Float16* fmap2[MM_MAXL];
+  float* offset[MM_MAXL];  // null = zero offsets for that level (altcorr)
+  const float* coords;
+  float* corr;
+  int H2[MM_MAXL], W2[MM_MAXL];
+  int L, B, S, H1, W1, blocks_x, blocks_y, xcd_map, vec_out;
+};
+
 // One wave = one workgroup = one 4 x 4 pixel block.  Lane layout outside the sweep: row = lane / 16 is a
 // pixel of the current pass (pass q serves block row q: pixel k = 4 q + row), j = lane % 16 carries the
 // taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes reduce inside 16-lane rows with DPP only.
 template <int R, int KS>
-__global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
-    const _Float16* __restrict__ fmap1, const _Float16* __restrict__ fmap2, const float* __restrict__ coords,
-    float* offset, float* __restrict__ corr, int B, int S, int H1, int W1, int H2, int W2, int blocks_x, int blocks_y,
-    int xcd_map, int vec_out) {
+__global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD, C = 32 * KS;
   constexpr int TI = (NT + 15) / 16;   // tap slots per lane
   constexpr int CEN = R * RD + R;      // centre tap
@@ -101,27 +114,39 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
   int* const pbox = reinterpret_cast<int*>(smem + MM_BP * MM_PP);     // [16][xlo,ylo,bw,bh]
   const int lane = threadIdx.x;
   const int lx = lane & 15, lg = lane >> 4;
+  const int B = p.B, S = p.S, H1 = p.H1, W1 = p.W1, blocks_x = p.blocks_x;
 
-  // ---- workgroup -> (edge, block) ----
+  // ---- workgroup -> (level, edge, block) ----
   int b, blk;
-  const int blocks = blocks_x * blocks_y;
-  if (xcd_map) {  // consecutive workgroup ids go to consecutive XCDs: keep an edge on one XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blocks = blocks_x * p.blocks_y;
+  const int per_level = (p.xcd_map ? ((B + 7) >> 3) * 8 : B) * blocks;
+  const int lvl = p.L > 1 ? (int)blockIdx.x / per_level : 0;
+  const int item = p.L > 1 ? (int)blockIdx.x - lvl * per_level : (int)blockIdx.x;
+  if (p.xcd_map) {  // consecutive workgroup ids go to consecutive XCDs: keep an edge on one XCD
+    const int xcd = item & 7, slot = item >> 3;
     b = (slot / blocks) * 8 + xcd;
     blk = slot % blocks;
     if (b >= B) return;
   } else {
-    b = blockIdx.x / blocks;
-    blk = blockIdx.x % blocks;
+    b = item / blocks;
+    blk = item % blocks;
   }
+  // per-level operands (uniform selects, no dynamic indexing of the argument struct)
+  const _Float16* fmap2 = p.fmap2[0];
+  float* offset = p.offset[0];
+  int H2 = p.H2[0], W2 = p.W2[0];
+#pragma unroll
+  for (int l = 1; l < MM_MAXL; l++)
+    if (lvl == l) { fmap2 = p.fmap2[l]; offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
+  const float cscale = __builtin_ldexpf(1.0f, -lvl);  // coords / 2^l (corr.py:197): exact in fp32
   const int n = blockIdx.y;
   const int by = blk / blocks_x, bx = blk % blocks_x;
   const size_t HW1 = (size_t)H1 * W1;
-  const _Float16* const F1 = fmap1 + (size_t)b * HW1 * C;
+  const _Float16* const F1 = p.fmap1 + (size_t)b * HW1 * C;
   const _Float16* const F2 = fmap2 + (size_t)b * H2 * W2 * C;
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets (altcorr)
   float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
-  const float2* const cbase = reinterpret_cast<const float2*>(coords) + ((size_t)b * S + n) * HW1;
+  const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
 
   MM_STAMP(0);
   // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested first, consumed by the sweep
@@ -149,6 +174,7 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
     const bool pv = h1 < H1 && w1r < W1;
     const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
     cvv[q] = cbase[pix];
+    cvv[q].x *= cscale; cvv[q].y *= cscale;
 #pragma unroll
     for (int i = 0; i < TI; i++) {
       const int t = lx + 16 * i;
@@ -326,14 +352,14 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float* const cb = corr + ((size_t)b * S + n) * NT * HW1;
+  float* const cb = p.corr + (((size_t)b * S + n) * p.L + lvl) * NT * HW1;
   for (int idx = lane; idx < NT * 4; idx += kWave) {
     const int t = idx >> 2, q = idx & 3;
     const int h1 = by * 4 + q, w1 = bx * 4;
     if (h1 >= H1) continue;
     const float4 v = *reinterpret_cast<const float4*>(outt + t * MM_OUTP + q * 4);
     float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
-    if (vec_out) {
+    if (p.vec_out) {
       *reinterpret_cast<float4*>(dst) = v;
     } else {
       dst[0] = v.x;
@@ -346,30 +372,30 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(
 }
 
 template <int R, int KS>
-static int launch_mfma(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
-                       int B, int S, int H1, int W1, int H2, int W2, hipStream_t st) {
+static int launch_mfma(MmParams p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)MM_LDS_FLOATS;
   auto kern = lowmem_mfma_kernel<R, KS>;
-  const int blocks_x = (W1 + 3) / 4, blocks_y = (H1 + 3) / 4;
-  const int blocks = blocks_x * blocks_y;
-  const int xcd_map = B >= 8 ? 1 : 0;
-  const size_t nwg = xcd_map ? (size_t)((B + 7) / 8) * 8 * blocks : (size_t)B * blocks;
+  p.blocks_x = (p.W1 + 3) / 4;
+  p.blocks_y = (p.H1 + 3) / 4;
+  const int blocks = p.blocks_x * p.blocks_y;
+  p.xcd_map = p.B >= 8 ? 1 : 0;
+  const size_t nwg = (size_t)p.L * (p.xcd_map ? (size_t)((p.B + 7) / 8) * 8 * blocks : (size_t)p.B * blocks);
   if (nwg >= (1u << 31)) return -1;
-  const int vec_out = (W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(corr) & 15) == 0);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)S), dim3(kWave), lds, st, fmap1, fmap2, coords, offset, corr, B,
-                     S, H1, W1, H2, W2, blocks_x, blocks_y, xcd_map, vec_out);
+  p.vec_out = (p.W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.corr) & 15) == 0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)p.S), dim3(kWave), lds, st, p);
   return launch_status();
 }
 
-// Returns -1 when this kernel does not serve the arguments (the caller then uses the VALU tile kernel).
-int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
-                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
-  const bool aligned = ((reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2)) & 15) == 0;
-  if (radius < 1 || radius > 3 || !aligned || S > 65535) return -1;
+static int mfma_dispatch(const MmParams& p, int C, int radius, hipStream_t st) {
+  uintptr_t al = reinterpret_cast<uintptr_t>(p.fmap1);
+  for (int l = 0; l < p.L; l++) al |= reinterpret_cast<uintptr_t>(p.fmap2[l]);
+  if (radius < 1 || radius > 3 || (al & 15) != 0 || p.S > 65535) return -1;
   if (C != 32 && C != 64 && C != 128 && C != 256) return -1;
-  if ((size_t)H2 * W2 * C >= (1u << 31) || (size_t)H1 * W1 * C >= (1u << 31) || H2 > 32767 || W2 > 32767) return -1;
+  if ((size_t)p.H1 * p.W1 * C >= (1u << 31)) return -1;
+  for (int l = 0; l < p.L; l++)
+    if ((size_t)p.H2[l] * p.W2[l] * C >= (1u << 31) || p.H2[l] > 32767 || p.W2[l] > 32767) return -1;
 #define LGU_MM_CASE(RV, KSV) \
-  if (radius == RV && C == 32 * KSV) return launch_mfma<RV, KSV>(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, st);
+  if (radius == RV && C == 32 * KSV) return launch_mfma<RV, KSV>(p, st);
   LGU_MM_CASE(3, 4) LGU_MM_CASE(1, 4) LGU_MM_CASE(2, 4)
   LGU_MM_CASE(3, 1) LGU_MM_CASE(1, 1) LGU_MM_CASE(2, 1)
   LGU_MM_CASE(3, 2) LGU_MM_CASE(1, 2) LGU_MM_CASE(2, 2)
@@ -378,7 +404,43 @@ int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const flo
   return -1;
 }
 
+// Returns -1 when this kernel does not serve the arguments (the caller then uses the VALU tile kernel).
+int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  MmParams p = {};
+  p.fmap1 = fmap1; p.fmap2[0] = fmap2; p.offset[0] = offset; p.coords = coords; p.corr = corr;
+  p.H2[0] = H2; p.W2[0] = W2;
+  p.L = 1; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
+  return mfma_dispatch(p, C, radius, st);
+}
+
 }  // namespace lgu
+
+extern "C" {
+
+int lgu_lowmem_pyramid_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
+                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, void* stream) {
+  using namespace lgu;
+  if (!fmap1 || !fmap2 || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
+  if (L < 1 || L > MM_MAXL || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
+  if ((long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
+  MmParams p = {};
+  p.fmap1 = static_cast<const _Float16*>(fmap1);
+  for (int l = 0; l < L; l++) {
+    if (!fmap2[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
+    p.fmap2[l] = static_cast<const _Float16*>(fmap2[l]);
+    p.offset[l] = offsets[l];
+    p.H2[l] = H2[l]; p.W2[l] = W2[l];
+  }
+  p.coords = coords; p.corr = out;
+  p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
+  if (B == 0) return LGU_OK;
+  const int rc = mfma_dispatch(p, C, radius, reinterpret_cast<hipStream_t>(stream));
+  return rc < 0 ? LGU_E_UNSUPPORTED : rc;
+}
+
+}  // extern "C"
 
 #ifdef LGU_MM_STAMPS
 // Diagnostic build only (tools/diag): never part of liblgu_corr.so.

@@ -186,9 +186,10 @@ def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
 
 
 def lowMem_defSample_mixed(fmap1, fmap2, coords, offset, radius):
-    """lowMem_defSample on HALF-precision feature maps with fp32 accumulation and output: bit-identical
-    to `lowMem_defSample(fmap1.float(), fmap2.float(), coords, offset, radius)` — which is what the
-    reference call site does (corr.py:209) — without materialising the float copies."""
+    """lowMem_defSample on HALF-precision feature maps with fp32 accumulation and output: equal to
+    `lowMem_defSample(fmap1.float(), fmap2.float(), coords, offset, radius)` — what the reference call site
+    does (corr.py:209) — up to fp32 summation order (the contraction runs on the matrix cores with exact half
+    products), without materialising the float copies."""
     _check_dtype(fmap1, "fmap1", torch.float16); _check_dtype(fmap2, "fmap2", torch.float16)
     _check(coords, "coords", offset, "offset")
     B, S, H1, W1, _ = coords.shape
@@ -206,7 +207,7 @@ def lowMem_defSample_mixed(fmap1, fmap2, coords, offset, radius):
 
 def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
     """altcorr_forward on HALF-precision feature maps, fp32 accumulation/output (= the reference call
-    site corr.py:202 on `.float()` copies, bit for bit)."""
+    site corr.py:202 on `.float()` copies, up to fp32 summation order)."""
     _check_dtype(fmap1, "fmap1", torch.float16); _check_dtype(fmap2, "fmap2", torch.float16)
     _check(coords, "coords")
     B, S, H1, W1, _ = coords.shape
@@ -220,6 +221,55 @@ def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
                                              radius, _stream(fmap1))
     _lib.check(rc, "altcorr_forward_mixed")
     return [corr]
+
+
+class LowmemPyramidPlan:
+    """The per-level loop of AltCorrBlock.corr_fn (reference corr.py:192-213) as ONE launch over half feature
+    maps (lgu_lowmem_pyramid_fwd_h16): level l samples fmap2s[l] at coords / 2^l with offsets[l] (None = zero
+    offsets) and writes channels l*rd*rd.. of the concatenated output (B, S, L*rd*rd, H1, W1).  The pointer
+    tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first call)
+    for channel counts / radii the matrix-core kernel does not serve."""
+
+    def __init__(self, fmap1, fmap2s, offsets, radius):
+        L = len(fmap2s)
+        if len(offsets) != L or not 1 <= L <= 4:
+            raise RuntimeError("LowmemPyramidPlan: need 1..4 levels and one offset entry (tensor or None) per level")
+        _check_dtype(fmap1, "fmap1", torch.float16)
+        for l, f in enumerate(fmap2s):
+            _check_dtype(f, "fmap2[%d]" % l, torch.float16)
+            if offsets[l] is not None:
+                _check(offsets[l], "offset[%d]" % l)
+        self._keep = (fmap1, list(fmap2s), list(offsets))
+        self.L, self.radius = L, radius
+        self.B, self.H1, self.W1, self.C = fmap1.shape
+        self.device = fmap1.device
+        self.NO = max([o.shape[0] for o in offsets if o is not None] or [self.B])
+        self._f2 = (_vp * L)(*[f.data_ptr() for f in fmap2s])
+        self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
+        self._h2 = (ctypes.c_int * L)(*[f.shape[1] for f in fmap2s])
+        self._w2 = (ctypes.c_int * L)(*[f.shape[2] for f in fmap2s])
+        self._fn = _lib.load().lgu_lowmem_pyramid_fwd_h16
+
+    def __call__(self, coords, out=None):
+        _check(coords, "coords")
+        B, S, H1, W1, _ = coords.shape
+        if (B, H1, W1) != (self.B, self.H1, self.W1):
+            raise RuntimeError("coords must be (B,S,H1,W1,2) for the planned feature maps")
+        ch = self.L * (2 * self.radius + 1) ** 2
+        if out is None:
+            out = torch.empty((B, S, ch, H1, W1), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
+        rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, B, S, H1, W1,
+                      self._h2, self._w2, self.C, self.NO, self.radius, torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "lowmem_pyramid_forward")
+        return out
+
+
+def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None):
+    """One-shot form of LowmemPyramidPlan."""
+    with torch.cuda.device(fmap1.device):
+        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius)(coords, out=out)
 
 
 PYR_PROBE, PYR_TILED = 1, 2  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)

@@ -780,3 +780,39 @@ def test_corrblock_layouts_agree_and_cat(lgu, monkeypatch):
         assert a._tiled and float((got - whole(coords)[0]).abs().max()) <= 2e-5
         sub = whole[torch.tensor([0, 2], device="cuda")]
         assert sub(coords[:, [0, 2]])[0].shape == (1, 2, 196, h, w)
+
+
+@pytest.mark.parametrize("cfg", [(3, 24, 32, 128, 3, 4), (9, 12, 20, 64, 3, 3), (2, 10, 13, 128, 2, 2), (1, 24, 32, 32, 1, 2)])
+def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg):
+    """lgu_lowmem_pyramid_fwd_h16 (all levels of AltCorrBlock.corr_fn in one launch, half feature maps) ==
+    the per-level mixed operator called L times with coords / 2^l, BIT FOR BIT, written at the right channels of
+    the concatenated tensor; None offsets == zero offset tensors; same in-place centre zeroing; level 0 also
+    against the oracle on the float copies."""
+    B, H, W, C, radius, L = cfg
+    rng = np.random.default_rng(500 + B + C)
+    rd = 2 * radius + 1
+    f1 = (torch.from_numpy(rng.standard_normal((B, H, W, C)).astype(np.float32)) * 0.125).cuda().half()
+    f2s = [(torch.from_numpy(rng.standard_normal((B, max(H >> l, 1), max(W >> l, 1), C)).astype(np.float32)) * 0.125).cuda().half()
+           for l in range(L)]
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    c_np = (np.stack([xs, ys], -1)[None, None].repeat(B, 0) + rng.standard_normal((B, 1, H, W, 2)) * 3).astype(np.float32)
+    coords = dev(c_np)
+    off_np = [(4 * np.tanh(rng.standard_normal((B, H, W, rd, rd, 2)))).astype(np.float32) if l < 2 else None for l in range(L)]
+    offs_a = [dev(o) if o is not None else None for o in off_np]
+    offs_b = [dev(o) if o is not None else torch.zeros(B, H, W, rd, rd, 2, device="cuda") for o in off_np]
+    got = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, offs_a, radius)
+    assert got.shape == (B, 1, L * rd * rd, H, W)
+    for l in range(L):
+        want, = lgu.ops.lowMem_defSample_mixed(f1, f2s[l], (coords / 2 ** l).contiguous(), offs_b[l], radius)
+        assert torch.equal(got[:, :, l * rd * rd:(l + 1) * rd * rd], want.view(B, 1, rd * rd, H, W)), l
+        if offs_a[l] is not None:
+            assert torch.equal(offs_a[l], offs_b[l])
+    ref0, = oracle.lowMem_defSample(host(f1.float()), host(f2s[0].float()), c_np, off_np[0].copy(), radius)
+    assert np.abs(host(got[:, :, :rd * rd]).reshape(ref0.shape) - ref0).max() <= 1e-5
+    # a plan is reusable and an unsupported channel count is reported, not mis-served
+    plan = lgu.ops.LowmemPyramidPlan(f1, f2s, offs_a, radius)
+    assert torch.equal(plan(coords), got)
+    with pytest.raises(lgu._lib.UnsupportedShape):   # 48 channels: not a matrix-core K multiple this kernel instantiates
+        lgu.ops.lowmem_pyramid_forward_mixed(torch.zeros(B, H, W, 48, device="cuda").half(),
+                                             [torch.zeros(B, f.shape[1], f.shape[2], 48, device="cuda").half() for f in f2s],
+                                             coords, offs_a, radius)

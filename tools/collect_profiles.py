@@ -85,12 +85,13 @@ json.dump(lowmem, open(os.path.join(P, "%s_lowmem_kernels.json" % tag), "w"), in
 b = json.load(open(os.path.join(G, "bench.json")))
 br = json.load(open(os.path.join(G, "bench_rowmajor.json")))
 bp = json.load(open(os.path.join(G, "bench_probe.json")))
+bl = json.load(open(os.path.join(G, "bench_lowmem.json")))
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
 keep = ("value", "ms_per_step", "roofline", "config")
 json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py (tiled pyramid), bench.py --layout rowmajor, "
                    "bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic for both layouts, low-memory kernel trace, "
                    "comparison with the reference kernels (oracle/_ref) on the same device",
-           "bench": b, "bench_rowmajor": {k: br[k] for k in keep}, "bench_probe": {k: bp[k] for k in keep},
+           "bench": b, "bench_rowmajor": {k: br[k] for k in keep}, "bench_probe": {k: bp[k] for k in keep}, "bench_lowmem_config4": bl,
            "kernel_stats_defcorr_tiled": dict(kern_t), "kernel_stats_defcorr_rowmajor": dict(kern_r),
            "traffic_tiled": traffic_t, "traffic_rowmajor": traffic_r, "lowmem_kernels": lowmem, "compare_ref": cmp_},
           open(os.path.join(P, "%s_final.json" % tag), "w"), indent=1)

@@ -27,3 +27,11 @@ for l in range(4):
     for _ in range(5):
         ops.lowMem_defSample_mixed(f1h, f2h, cl, off0 if l < 2 else zero, 3)
 torch.cuda.synchronize()
+# all four levels in one launch (what AltCorrBlock issues for half feature buffers)
+f1h = f1.half()
+f2hs = [(torch.randn(B, H >> l, W >> l, C, device=dev) * 0.125).half().contiguous() for l in range(4)]
+off1 = ((4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device=dev)) + off0) / 2).contiguous()
+plan = ops.LowmemPyramidPlan(f1h, f2hs, [off0, off1, None, None], 3)
+for _ in range(5):
+    plan(base.contiguous())
+torch.cuda.synchronize()
