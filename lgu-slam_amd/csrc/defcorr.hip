@@ -457,19 +457,24 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
       off[k][l] = make_float2(0.0f, 0.0f);
-      if (!((ZMASK >> l) & 1) && l < p.L && pv && tap && !centre)
+      if (!((ZMASK >> l) & 1) && l < p.L && pv && tap)
         off[k][l] = reinterpret_cast<const float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane];
     }
   }
-  if (centre) {  // reference side effect (defCorrSample_kernel.cu:51-52)
+  if (centre) {
+    // reference side effect (defCorrSample_kernel.cu:51-52): offset[centre] = 0.  The tensor persists across the
+    // 8-16 lookups of one volume, so after the first call the centre already holds +0: it is stored only when its
+    // bits are not already that (same final tensor, no 32-byte partial write per pixel-level in the steady state)
 #pragma unroll
     for (int k = 0; k < GP; k++) {
       const int px = xbase + w * GP + k;
-      if (px >= p.W1) continue;
 #pragma unroll
-      for (int l = 0; l < FASTL; l++)
-        if (!((ZMASK >> l) & 1) && l < p.L)
+      for (int l = 0; l < FASTL; l++) {
+        if (((ZMASK >> l) & 1) || l >= p.L || px >= p.W1) continue;
+        if ((__builtin_bit_cast(unsigned, off[k][l].x) | __builtin_bit_cast(unsigned, off[k][l].y)) != 0u)
           reinterpret_cast<float2*>(p.off[l] + (row_pix + px) * (NT * 2))[lane] = make_float2(0.0f, 0.0f);
+        off[k][l] = make_float2(0.0f, 0.0f);
+      }
     }
   }
   float2 cs[GP][FASTL];

@@ -179,8 +179,19 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
     for (int i = 0; i < TI; i++) {
       const int t = lx + 16 * i;
       o0[q][i] = make_float2(0.f, 0.f);
-      if (obase && pv && t < NT && t != CEN) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
-      if (obase && pv && t == CEN) reinterpret_cast<float2*>(obase + pix * NT * 2)[t] = make_float2(0.f, 0.f);  // :80-81
+      if (obase && pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
+    }
+  }
+  if (obase) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int h1 = by * 4 + q;
+      constexpr int ci = CEN / 16;
+      if (lx == CEN % 16 && h1 < H1 && w1r < W1) {
+        if ((__builtin_bit_cast(unsigned, o0[q][ci].x) | __builtin_bit_cast(unsigned, o0[q][ci].y)) != 0u)
+          reinterpret_cast<float2*>(obase + ((size_t)h1 * W1 + w1r) * NT * 2)[CEN] = make_float2(0.f, 0.f);
+        o0[q][ci] = make_float2(0.f, 0.f);
+      }
     }
   }
   int blo[4], bwh[4];  // per pass, row-uniform: packed (xlo, ylo); bw | bh << 8 (0 = no patch) | fallback << 16
