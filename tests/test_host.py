@@ -191,3 +191,40 @@ def test_sharded_edge_set_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res) and sum(res[0][2]) == 14
+
+
+def test_tiled_layout_host_logic(lgu):
+    """Pure host side of the tiled slice layout: shapes, logical-size checks, and a numpy restatement of the
+    address formula of include/lgu_corr.h (LGU_PYR_TILED) that round-trips every element of a padded slice."""
+    import numpy as np
+    ops = lgu.ops
+    assert ops.tiled_shape(2, 48, 64, 48, 64) == (2, 48, 64, 12, 8, 4, 8)
+    assert ops.tiled_shape(1, 3, 5, 6, 8) == (1, 3, 5, 2, 1, 4, 8)      # 6 rows pad to 8
+    assert ops.tiled_shape(1, 3, 5, 15, 20) == (1, 3, 5, 4, 3, 4, 8)    # 15x20 pads to 16x24
+    t = torch.zeros(ops.tiled_shape(1, 2, 2, 6, 8))
+    assert ops._level_dims([t], True, [(6, 8)]) == ([6], [8])
+    assert ops._level_dims([t], True, None) == ([8], [8])              # unpadded logical size assumed
+    with pytest.raises(RuntimeError, match="tiled pyramid level"):
+        ops._level_dims([torch.zeros(1, 2, 2, 6, 8)], True, [(6, 8)])   # row-major tensor passed as tiled
+    with pytest.raises(RuntimeError, match="tiled pyramid level"):
+        ops._level_dims([t], True, [(12, 8)])                           # logical size that does not match the tiles
+    H2, W2 = 15, 20
+    tpr = -(-W2 // 8)
+    y, x = np.meshgrid(np.arange(H2), np.arange(W2), indexing="ij")
+    pos = ((y // 4) * tpr + x // 8) * 32 + (y % 4) * 8 + x % 8
+    assert len(np.unique(pos)) == H2 * W2 and pos.max() < (-(-H2 // 4)) * tpr * 32
+    # separability used by the kernel: the +1 neighbours are one add away
+    sx = np.where(x % 8 == 7, 25, 1)
+    sy = np.where(y % 4 == 3, tpr * 32 - 24, 8)
+    assert np.array_equal((pos + sx)[:, :-1], pos[:, 1:]) and np.array_equal((pos + sy)[:-1], pos[1:])
+
+
+def test_lowmem_plan_argument_checks(lgu):
+    ops = lgu.ops
+    h = torch.zeros(1, 4, 4, 32, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="1..4 levels"):
+        ops.LowmemPyramidPlan(h, [h] * 5, [None] * 5, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.LowmemPyramidPlan(h, [h], [None], 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback|expected scalar type"):
+        ops.LowmemPyramidPlan(h.float(), [h], [None], 3)
