@@ -130,7 +130,12 @@ int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H
 
 /* ---- low-memory (on-the-fly correlation) path ---------------------------------- */
 
-/* defCorrSample.lowMem_defSample        (droid.cpp:124-136, lowMem_defSample.cu:27-134,137-168).
+/* The channel contraction of the two forward operators below runs on the matrix cores for radius 1..3 and
+ * C in {16, 32, 64, 128} (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 fmaf-chain accumulation; the channel
+ * summation order differs from the reference's, results agree to fp32 rounding, tests: 1e-5); other shapes take
+ * VALU kernels.
+ *
+ * defCorrSample.lowMem_defSample        (droid.cpp:124-136, lowMem_defSample.cu:27-134,137-168).
  *   fmap1 (B,H1,W1,C)  fmap2 (B,H2,W2,C)  coords (B,S,H1,W1,2) [x,y interleaved]
  *   offset (NO,H1,W1,rd,rd,2) IN/OUT — indexed with b*s exactly as the reference does
  *   (lowMem_defSample.cu:80-83), i.e. offset[0] for every b when S == 1;
@@ -182,6 +187,13 @@ int lgu_altcorr_fwd_h16(const void* fmap1_half, const void* fmap2_half, const fl
  * (lgu_altcorr_fwd_h16) whose mask the caller folds into offsets[1] first.  Requires C in {32,64,128,256} and
  * radius in 1..3, otherwise LGU_E_UNSUPPORTED (compose the per-level entries instead). */
 int lgu_lowmem_pyramid_fwd_h16(const void* fmap1_half, const void* const* fmap2_half, const float* coords,
+                               float* const* offsets, float* out,
+                               int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, void* stream);
+
+/* The same for float feature maps (exact fp32 products and sums on v_mfma_f32_16x16x4_f32);
+ * requires C in {16, 32, 64, 128}. */
+int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords,
                                float* const* offsets, float* out,
                                int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
                                int radius, void* stream);

@@ -260,15 +260,15 @@ class AltCorrBlock:
         # operators accumulate in fp32 and equal the reference's `.float()` call sites bit for bit.
         mixed = f1.dtype == torch.float16
         f1 = f1.contiguous() if mixed else f1.float().contiguous()
-        if mixed and S == 1 and B == 1 and self.num_levels >= 2:
-            # half features, one sample per pixel (the SLAM system's case): the level-1 probe, then ALL levels in
-            # one launch written straight into the concatenated tensor (ops.LowmemPyramidPlan); levels whose
-            # offsets are zero by construction read no offset tensor at all
+        if S == 1 and B == 1 and self.num_levels >= 2:
+            # one sample per pixel (the SLAM system's case): the level-1 probe, then ALL levels in one launch
+            # written straight into the concatenated tensor (ops.LowmemPyramidPlan); levels whose offsets are
+            # zero by construction read no offset tensor at all.  Half feature buffers stay half.
             try:
-                f2s = [self.pyramid[i][:, jj].reshape((B * N,) + self.pyramid[i].shape[2:]).contiguous()
-                       for i in range(self.num_levels)]
+                f2s = [self.pyramid[i][:, jj].reshape((B * N,) + self.pyramid[i].shape[2:]) for i in range(self.num_levels)]
+                f2s = [f.contiguous() if mixed else f.float().contiguous() for f in f2s]
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
-                probe, = ops.altcorr_forward_mixed(f1, f2s[1], (c0 / 2).contiguous(), 1)
+                probe, = (ops.altcorr_forward_mixed if mixed else ops.altcorr_forward)(f1, f2s[1], (c0 / 2).contiguous(), 1)
                 probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
                 mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
                 self.offset[1] = self.offset[1] * mask

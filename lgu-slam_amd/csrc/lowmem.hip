@@ -266,6 +266,9 @@ __global__ __launch_bounds__(LM_WAVES * kWave) void altcorr_bwd_kernel(const flo
   }
 }
 
+// lowmem_mfma.hip: fp32 matrix-core kernel (v_mfma_f32_16x16x4_f32); -1 = shape not served
+int lowmem_mfma_dispatch_f32(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr,
+                             int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st);
 // lowmem_tile.hip
 int lowmem_tile_dispatch(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr, int B,
                          int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st);
@@ -301,8 +304,14 @@ int lgu_lowmem_defsample_fwd_f32(const float* fmap1, const float* fmap2, const f
   if (!offset || (long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
   if (B == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // LGU_LOWMEM_VARIANT (debug/A-B only): 0 = tile-staged kernel, 1 = wave-per-pixel kernel
-  if (env_int("LGU_LOWMEM_VARIANT", 0) == 0) {
+  // LGU_LOWMEM_VARIANT (debug/A-B only): 0 = matrix-core kernel (fp32 MFMA), 2 = tile-staged VALU kernel,
+  // 1 = wave-per-pixel kernel; each falls through to the next for shapes it does not serve
+  const int variant = env_int("LGU_LOWMEM_VARIANT", 0);
+  if (variant == 0) {
+    rc = lowmem_mfma_dispatch_f32(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
+    if (rc >= 0) return rc;
+  }
+  if (variant == 0 || variant == 2) {
     rc = lowmem_tile_dispatch(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, radius, st);
     if (rc >= 0) return rc;
   }
@@ -329,7 +338,12 @@ int lgu_altcorr_fwd_f32(const float* fmap1, const float* fmap2, const float* coo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // altcorr_forward == lowMem_defSample with zero offsets (same per-corner zero padding, same
   // [ix][iy] channel order): the tile-staged kernel serves it with a null offset pointer
-  if (env_int("LGU_LOWMEM_VARIANT", 0) == 0 && radius >= 1) {
+  const int variant = env_int("LGU_LOWMEM_VARIANT", 0);
+  if (variant == 0 && radius >= 1) {
+    rc = lowmem_mfma_dispatch_f32(fmap1, fmap2, coords, nullptr, corr, B, S, H1, W1, H2, W2, C, radius, st);
+    if (rc >= 0) return rc;
+  }
+  if ((variant == 0 || variant == 2) && radius >= 1) {
     rc = lowmem_tile_dispatch(fmap1, fmap2, coords, nullptr, corr, B, S, H1, W1, H2, W2, C, radius, st);
     if (rc >= 0) return rc;
   }

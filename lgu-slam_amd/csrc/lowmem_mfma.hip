@@ -38,21 +38,50 @@ constexpr int MM_PP = MM_BOX * MM_BOX + 4;  // patch pitch per pixel: the 4 pixe
 constexpr int MM_OUTP = 20;          // output transpose pitch (16 pixels + pad, 16-byte aligned rows)
 constexpr int MM_LDS_FLOATS = MM_BP * MM_PP + MM_BP * 4;
 
-__device__ __forceinline__ float dot8_h(const half8v& f, const half8v& a, float s) {
+// Element-type traits.  One k-step covers CPS channels; lane (lg, lx) holds EPL consecutive channels starting at
+// EPL * lg of row/column lx.  half: one v_mfma_f32_16x16x32_f16 per step.  float: four v_mfma_f32_16x16x4_f32 per
+// step (component t of the lane's float4 is k-slot lg of MFMA t) — exact fp32, a k-ordered fmaf chain per the ISA,
+// at the fp32 matrix rate (= the packed-VALU peak, but without the per-product LDS reads and VALU issue of the
+// tile kernel).
+template <typename T> struct MmT;
+template <> struct MmT<_Float16> {
+  typedef half8v frag;
+  static constexpr int CPS = 32, EPL = 8;
+  static __device__ __forceinline__ f32x4v mma(const frag& a, const frag& b, f32x4v d) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float dot(const frag& f, const frag& a, float s) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
-  return s;
-}
+    for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
+    return s;
+  }
+};
+template <> struct MmT<float> {
+  typedef f32x4v frag;
+  static constexpr int CPS = 16, EPL = 4;
+  static __device__ __forceinline__ f32x4v mma(const frag& a, const frag& b, f32x4v d) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], d, 0, 0, 0);
+    return d;
+  }
+  static __device__ __forceinline__ float dot(const frag& f, const frag& a, float s) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __builtin_fmaf(f[i], a[i], s);
+    return s;
+  }
+};
 
 // Fallback for boxes larger than the patch: the four corner dots of one tap straight from memory.
-__device__ __noinline__ float4 corner_dots_h(const _Float16* f1p, const _Float16* p11, int C, int W2, int mask) {
+template <typename T>
+__device__ __noinline__ float4 corner_dots(const T* f1p, const T* p11, int C, int W2, int mask) {
+  typedef typename MmT<T>::frag frag;
   float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-  for (int c = 0; c < C; c += 8) {
-    const half8v f = *reinterpret_cast<const half8v*>(f1p + c);
-    if (mask & 1) q11 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + c), q11);
-    if (mask & 2) q21 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + C + c), q21);
-    if (mask & 4) q12 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + (size_t)W2 * C + c), q12);
-    if (mask & 8) q22 = dot8_h(f, *reinterpret_cast<const half8v*>(p11 + (size_t)W2 * C + C + c), q22);
+  for (int c = 0; c < C; c += MmT<T>::EPL) {
+    const frag f = *reinterpret_cast<const frag*>(f1p + c);
+    if (mask & 1) q11 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + c), q11);
+    if (mask & 2) q21 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + C + c), q21);
+    if (mask & 4) q12 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + (size_t)W2 * C + c), q12);
+    if (mask & 8) q22 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + (size_t)W2 * C + C + c), q22);
   }
   return make_float4(q11, q21, q12, q22);
 }
@@ -91,8 +120,8 @@ constexpr int MM_MAXL = 4;  // pyramid levels one launch can serve
 // (the largest windows) first, level l samples fmap2[l] at coords / 2^l with offset[l] and writes channels
 // l*NT .. (l+1)*NT - 1 of the concatenated output.
 struct MmParams {
-  const _Float16* fmap1;
-  const _Float16* fmap2[MM_MAXL];
+  const void* fmap1;  // element type = the kernel's T (half or float)
+  const void* fmap2[MM_MAXL];
   float* offset[MM_MAXL];  // null = zero offsets for that level (altcorr)
   const float* coords;
   float* corr;
@@ -103,12 +132,15 @@ struct MmParams {
 // One wave = one workgroup = one 4 x 4 pixel block.  Lane layout outside the sweep: row = lane / 16 is a
 // pixel of the current pass (pass q serves block row q: pixel k = 4 q + row), j = lane % 16 carries the
 // taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes reduce inside 16-lane rows with DPP only.
-template <int R, int KS>
+template <int R, int KS, typename T>
 __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p) {
-  constexpr int RD = 2 * R + 1, NT = RD * RD, C = 32 * KS;
+  typedef typename MmT<T>::frag frag;
+  constexpr int CPS = MmT<T>::CPS, EPL = MmT<T>::EPL;
+  constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
   constexpr int TI = (NT + 15) / 16;   // tap slots per lane
   constexpr int CEN = R * RD + R;      // centre tap
   constexpr int MM_PF = KS <= 4 ? 4 : 2;  // position groups in flight (16 bytes x KS per lane each)
+  static_assert(sizeof(frag) == 16, "one 16-byte load per lane and k-step");
   extern __shared__ float smem[];
   float* const patch = smem;                                          // [16][MM_PP]
   int* const pbox = reinterpret_cast<int*>(smem + MM_BP * MM_PP);     // [16][xlo,ylo,bw,bh]
@@ -132,31 +164,31 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
     blk = item % blocks;
   }
   // per-level operands (uniform selects, no dynamic indexing of the argument struct)
-  const _Float16* fmap2 = p.fmap2[0];
+  const T* fmap2 = static_cast<const T*>(p.fmap2[0]);
   float* offset = p.offset[0];
   int H2 = p.H2[0], W2 = p.W2[0];
 #pragma unroll
   for (int l = 1; l < MM_MAXL; l++)
-    if (lvl == l) { fmap2 = p.fmap2[l]; offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
+    if (lvl == l) { fmap2 = static_cast<const T*>(p.fmap2[l]); offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
   const float cscale = __builtin_ldexpf(1.0f, -lvl);  // coords / 2^l (corr.py:197): exact in fp32
   const int n = blockIdx.y;
   const int by = blk / blocks_x, bx = blk % blocks_x;
   const size_t HW1 = (size_t)H1 * W1;
-  const _Float16* const F1 = p.fmap1 + (size_t)b * HW1 * C;
-  const _Float16* const F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  const T* const F1 = static_cast<const T*>(p.fmap1) + (size_t)b * HW1 * C;
+  const T* const F2 = fmap2 + (size_t)b * H2 * W2 * C;
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets (altcorr)
   float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
   const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
 
   MM_STAMP(0);
   // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested first, consumed by the sweep
-  half8v a[KS];
+  frag a[KS];
   {
     int h1 = by * 4 + (lx >> 2), w1 = bx * 4 + (lx & 3);
     h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
-    const _Float16* ap = F1 + ((size_t)h1 * W1 + w1) * C + 8 * lg;
+    const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
 #pragma unroll
-    for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const half8v*>(ap + 32 * s);
+    for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const frag*>(ap + CPS * s);
   }
   // ---- phase 0: sample positions and tap boxes (4 pixels per pass, one per lane row) ----
   const int w1r = bx * 4 + lg;  // this lane row's pixel column
@@ -256,19 +288,19 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
     auto bptr = [&](int y, int gx0) {
       int x = gx0 + lx;
       x = x < W2 ? x : W2 - 1;  // padded positions re-read the last column; their results land in no box
-      return F2 + ((size_t)(y * W2 + x)) * C + 8 * lg;
+      return F2 + ((size_t)(y * W2 + x)) * C + EPL * lg;
     };
     // MM_PF groups in flight: slot j holds iteration it + j; it is refilled for it + j + MM_PF right after use.
     // (The sweep is bound by the L2 -> CU read rate, ~70 GB/s per CU; a hand-counted s_waitcnt variant with
     // unconditional loads kept more loads in flight and was not faster: profiles/README.md.)
-    half8v bq[MM_PF][KS];
+    frag bq[MM_PF][KS];
     int yl = UY0, gxl = UX0;  // load cursor
 #pragma unroll
     for (int j = 0; j < MM_PF; j++) {
       if (j < nit) {
-        const _Float16* p = bptr(yl, gxl);
+        const T* p = bptr(yl, gxl);
 #pragma unroll
-        for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const half8v*>(p + 32 * s);
+        for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + CPS * s);
         gxl += 16;
         if (gxl > UX1) { gxl = UX0; yl++; }
       }
@@ -281,11 +313,11 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
         if (it + j < nit) {  // wave-uniform
           f32x4v d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < KS; s++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], bq[j][s], d, 0, 0, 0);
+          for (int s = 0; s < KS; s++) d = MmT<T>::mma(a[s], bq[j][s], d);
           if (it + j + MM_PF < nit) {
-            const _Float16* p = bptr(yl, gxl);
+            const T* p = bptr(yl, gxl);
 #pragma unroll
-            for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const half8v*>(p + 32 * s);
+            for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + CPS * s);
             gxl += 16;
             if (gxl > UX1) { gxl = UX0; yl++; }
           }
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
         if (b12) q12 = D[MM_BOX];
         if (b22) q22 = D[MM_BOX + 1];
       } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
-        const float4 qq = corner_dots_h(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
+        const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
                                         (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0));
         q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
       }
@@ -382,10 +414,10 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
   MM_STAMP(5);
 }
 
-template <int R, int KS>
+template <int R, int KS, typename T>
 static int launch_mfma(MmParams p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)MM_LDS_FLOATS;
-  auto kern = lowmem_mfma_kernel<R, KS>;
+  auto kern = lowmem_mfma_kernel<R, KS, T>;
   p.blocks_x = (p.W1 + 3) / 4;
   p.blocks_y = (p.H1 + 3) / 4;
   const int blocks = p.blocks_x * p.blocks_y;
@@ -397,16 +429,17 @@ static int launch_mfma(MmParams p, hipStream_t st) {
   return launch_status();
 }
 
+template <typename T>
 static int mfma_dispatch(const MmParams& p, int C, int radius, hipStream_t st) {
   uintptr_t al = reinterpret_cast<uintptr_t>(p.fmap1);
   for (int l = 0; l < p.L; l++) al |= reinterpret_cast<uintptr_t>(p.fmap2[l]);
   if (radius < 1 || radius > 3 || (al & 15) != 0 || p.S > 65535) return -1;
-  if (C != 32 && C != 64 && C != 128 && C != 256) return -1;
   if ((size_t)p.H1 * p.W1 * C >= (1u << 31)) return -1;
   for (int l = 0; l < p.L; l++)
     if ((size_t)p.H2[l] * p.W2[l] * C >= (1u << 31) || p.H2[l] > 32767 || p.W2[l] > 32767) return -1;
+  constexpr int cps = MmT<T>::CPS;  // half: C in {32,64,128,256}; float: C in {16,32,64,128}
 #define LGU_MM_CASE(RV, KSV) \
-  if (radius == RV && C == 32 * KSV) return launch_mfma<RV, KSV>(p, st);
+  if (radius == RV && C == cps * KSV) return launch_mfma<RV, KSV, T>(p, st);
   LGU_MM_CASE(3, 4) LGU_MM_CASE(1, 4) LGU_MM_CASE(2, 4)
   LGU_MM_CASE(3, 1) LGU_MM_CASE(1, 1) LGU_MM_CASE(2, 1)
   LGU_MM_CASE(3, 2) LGU_MM_CASE(1, 2) LGU_MM_CASE(2, 2)
@@ -415,40 +448,62 @@ static int mfma_dispatch(const MmParams& p, int C, int radius, hipStream_t st) {
   return -1;
 }
 
-// Returns -1 when this kernel does not serve the arguments (the caller then uses the VALU tile kernel).
-int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
-                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+// Return -1 when the matrix-core kernel does not serve the arguments (the caller then uses the VALU tile kernel).
+static MmParams single_level(const void* fmap1, const void* fmap2, const float* coords, float* offset, float* corr, int B,
+                             int S, int H1, int W1, int H2, int W2) {
   MmParams p = {};
   p.fmap1 = fmap1; p.fmap2[0] = fmap2; p.offset[0] = offset; p.coords = coords; p.corr = corr;
   p.H2[0] = H2; p.W2[0] = W2;
   p.L = 1; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
-  return mfma_dispatch(p, C, radius, st);
+  return p;
+}
+int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
+                         int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  return mfma_dispatch<_Float16>(single_level(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2), C, radius, st);
+}
+int lowmem_mfma_dispatch_f32(const float* fmap1, const float* fmap2, const float* coords, float* offset, float* corr,
+                             int B, int S, int H1, int W1, int H2, int W2, int C, int radius, hipStream_t st) {
+  return mfma_dispatch<float>(single_level(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2), C, radius, st);
 }
 
 }  // namespace lgu
 
 extern "C" {
 
-int lgu_lowmem_pyramid_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
-                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                               int radius, void* stream) {
+static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
+                         float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                         int radius, void* stream) {
   using namespace lgu;
   if (!fmap1 || !fmap2 || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
   if (L < 1 || L > MM_MAXL || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
   if ((long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
   MmParams p = {};
-  p.fmap1 = static_cast<const _Float16*>(fmap1);
+  p.fmap1 = fmap1;
   for (int l = 0; l < L; l++) {
     if (!fmap2[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
-    p.fmap2[l] = static_cast<const _Float16*>(fmap2[l]);
+    p.fmap2[l] = fmap2[l];
     p.offset[l] = offsets[l];
     p.H2[l] = H2[l]; p.W2[l] = W2[l];
   }
   p.coords = coords; p.corr = out;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   if (B == 0) return LGU_OK;
-  const int rc = mfma_dispatch(p, C, radius, reinterpret_cast<hipStream_t>(stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rc = half ? mfma_dispatch<_Float16>(p, C, radius, st) : mfma_dispatch<float>(p, C, radius, st);
   return rc < 0 ? LGU_E_UNSUPPORTED : rc;
+}
+
+int lgu_lowmem_pyramid_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
+                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, void* stream) {
+  return pyramid_entry(true, fmap1, fmap2, coords, offsets, out, L, B, S, H1, W1, H2, W2, C, NO, radius, stream);
+}
+
+int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords, float* const* offsets,
+                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, void* stream) {
+  return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, B, S, H1, W1, H2,
+                       W2, C, NO, radius, stream);
 }
 
 }  // extern "C"

@@ -224,8 +224,8 @@ def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
 
 
 class LowmemPyramidPlan:
-    """The per-level loop of AltCorrBlock.corr_fn (reference corr.py:192-213) as ONE launch over half feature
-    maps (lgu_lowmem_pyramid_fwd_h16): level l samples fmap2s[l] at coords / 2^l with offsets[l] (None = zero
+    """The per-level loop of AltCorrBlock.corr_fn (reference corr.py:192-213) as ONE launch over half or float
+    feature maps (lgu_lowmem_pyramid_fwd_h16 / _f32): level l samples fmap2s[l] at coords / 2^l with offsets[l] (None = zero
     offsets) and writes channels l*rd*rd.. of the concatenated output (B, S, L*rd*rd, H1, W1).  The pointer
     tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first call)
     for channel counts / radii the matrix-core kernel does not serve."""
@@ -234,9 +234,10 @@ class LowmemPyramidPlan:
         L = len(fmap2s)
         if len(offsets) != L or not 1 <= L <= 4:
             raise RuntimeError("LowmemPyramidPlan: need 1..4 levels and one offset entry (tensor or None) per level")
-        _check_dtype(fmap1, "fmap1", torch.float16)
+        dt = torch.float16 if fmap1.dtype == torch.float16 else torch.float32
+        _check_dtype(fmap1, "fmap1", dt)
         for l, f in enumerate(fmap2s):
-            _check_dtype(f, "fmap2[%d]" % l, torch.float16)
+            _check_dtype(f, "fmap2[%d]" % l, dt)
             if offsets[l] is not None:
                 _check(offsets[l], "offset[%d]" % l)
         self._keep = (fmap1, list(fmap2s), list(offsets))
@@ -248,7 +249,7 @@ class LowmemPyramidPlan:
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
         self._h2 = (ctypes.c_int * L)(*[f.shape[1] for f in fmap2s])
         self._w2 = (ctypes.c_int * L)(*[f.shape[2] for f in fmap2s])
-        self._fn = _lib.load().lgu_lowmem_pyramid_fwd_h16
+        self._fn = _lib.load().lgu_lowmem_pyramid_fwd_h16 if dt == torch.float16 else _lib.load().lgu_lowmem_pyramid_fwd_f32
 
     def __call__(self, coords, out=None):
         _check(coords, "coords")
@@ -267,7 +268,7 @@ class LowmemPyramidPlan:
 
 
 def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None):
-    """One-shot form of LowmemPyramidPlan."""
+    """One-shot form of LowmemPyramidPlan (half or float feature maps)."""
     with torch.cuda.device(fmap1.device):
         return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius)(coords, out=out)
 

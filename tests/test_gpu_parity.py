@@ -233,7 +233,7 @@ LOWMEM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])   # 0 = fp32 matrix-core kernel, 2 = VALU tile kernel, 1 = wave-per-pixel kernel
 @pytest.mark.parametrize("cfg", LOWMEM_CASES)
 def test_lowmem_defsample(lgu, oracle, cfg, variant):
     B, S, H1, W1, H2, W2, C, radius, sigma, scale, osc = cfg
@@ -257,7 +257,7 @@ def test_lowmem_defsample(lgu, oracle, cfg, variant):
         os.environ.pop("LGU_LOWMEM_VARIANT", None)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("cfg", [(3, 1, 12, 16, 6, 8, 128, 1, 3.0, 0.5), (2, 2, 8, 16, 8, 16, 64, 3, 5.0, 1.0),
                                  (1, 1, 15, 20, 7, 10, 128, 1, 8.0, 0.5), (2, 1, 60, 80, 30, 40, 128, 1, 3.0, 0.5)])
 def test_altcorr_forward_backward(lgu, oracle, cfg, variant):
@@ -379,8 +379,12 @@ def test_mixed_precision_lowmem_equals_the_float_call_site(lgu, oracle, cfg, var
         a, = lgu.ops.altcorr_forward_mixed(f1h, f2h, coords, 1)
     finally:
         os.environ.pop("LGU_LOWMEM_H16_VARIANT")
-    want, = lgu.ops.lowMem_defSample(f1h.float(), f2h.float(), coords, o_f, radius)
-    b, = lgu.ops.altcorr_forward(f1h.float(), f2h.float(), coords, 1)
+    os.environ["LGU_LOWMEM_VARIANT"] = "2"   # the VALU tile kernel over the float copies: the summation order variant 1 shares
+    try:
+        want, = lgu.ops.lowMem_defSample(f1h.float(), f2h.float(), coords, o_f, radius)
+        b, = lgu.ops.altcorr_forward(f1h.float(), f2h.float(), coords, 1)
+    finally:
+        os.environ.pop("LGU_LOWMEM_VARIANT")
     assert got.dtype == torch.float32 and torch.equal(o_m, o_f)
     if variant == 1:
         assert torch.equal(got, want) and torch.equal(a, b)
@@ -394,7 +398,7 @@ def test_mixed_precision_lowmem_equals_the_float_call_site(lgu, oracle, cfg, var
 
 def test_lowmem_backend_scale_tile_kernel_equals_wave_kernel(lgu):
     """BASELINE config 5 scale per GPU (250 edges x 60x80, C=128; here B=192 to bound the test's
-    memory): the tile-staged kernel and the independent wave-per-pixel kernel agree on the LAST edges
+    memory): the production (matrix-core) kernel and the independent wave-per-pixel kernel agree on the LAST edges
     (largest addresses) — guards the 32-bit in-edge offsets and the grid decomposition."""
     torch.manual_seed(13)
     B, H, W, C = 192, 60, 80, 128
@@ -782,17 +786,20 @@ def test_corrblock_layouts_agree_and_cat(lgu, monkeypatch):
         assert sub(coords[:, [0, 2]])[0].shape == (1, 2, 196, h, w)
 
 
+@pytest.mark.parametrize("half", [True, False])
 @pytest.mark.parametrize("cfg", [(3, 24, 32, 128, 3, 4), (9, 12, 20, 64, 3, 3), (2, 10, 13, 128, 2, 2), (1, 24, 32, 32, 1, 2)])
-def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg):
-    """lgu_lowmem_pyramid_fwd_h16 (all levels of AltCorrBlock.corr_fn in one launch, half feature maps) ==
-    the per-level mixed operator called L times with coords / 2^l, BIT FOR BIT, written at the right channels of
-    the concatenated tensor; None offsets == zero offset tensors; same in-place centre zeroing; level 0 also
-    against the oracle on the float copies."""
+def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg, half):
+    """lgu_lowmem_pyramid_fwd_h16 / _f32 (all levels of AltCorrBlock.corr_fn in one launch) == the per-level
+    operator called L times with coords / 2^l, BIT FOR BIT, written at the right channels of the concatenated
+    tensor; None offsets == zero offset tensors; same in-place centre zeroing; level 0 also against the oracle
+    on the float copies."""
     B, H, W, C, radius, L = cfg
+    cast = (lambda t: t.half()) if half else (lambda t: t)
+    per_level = lgu.ops.lowMem_defSample_mixed if half else lgu.ops.lowMem_defSample
     rng = np.random.default_rng(500 + B + C)
     rd = 2 * radius + 1
-    f1 = (torch.from_numpy(rng.standard_normal((B, H, W, C)).astype(np.float32)) * 0.125).cuda().half()
-    f2s = [(torch.from_numpy(rng.standard_normal((B, max(H >> l, 1), max(W >> l, 1), C)).astype(np.float32)) * 0.125).cuda().half()
+    f1 = cast((torch.from_numpy(rng.standard_normal((B, H, W, C)).astype(np.float32)) * 0.125).cuda())
+    f2s = [cast((torch.from_numpy(rng.standard_normal((B, max(H >> l, 1), max(W >> l, 1), C)).astype(np.float32)) * 0.125).cuda())
            for l in range(L)]
     ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
     c_np = (np.stack([xs, ys], -1)[None, None].repeat(B, 0) + rng.standard_normal((B, 1, H, W, 2)) * 3).astype(np.float32)
@@ -803,7 +810,7 @@ def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg
     got = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, offs_a, radius)
     assert got.shape == (B, 1, L * rd * rd, H, W)
     for l in range(L):
-        want, = lgu.ops.lowMem_defSample_mixed(f1, f2s[l], (coords / 2 ** l).contiguous(), offs_b[l], radius)
+        want, = per_level(f1, f2s[l], (coords / 2 ** l).contiguous(), offs_b[l], radius)
         assert torch.equal(got[:, :, l * rd * rd:(l + 1) * rd * rd], want.view(B, 1, rd * rd, H, W)), l
         if offs_a[l] is not None:
             assert torch.equal(offs_a[l], offs_b[l])
@@ -813,6 +820,6 @@ def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg
     plan = lgu.ops.LowmemPyramidPlan(f1, f2s, offs_a, radius)
     assert torch.equal(plan(coords), got)
     with pytest.raises(lgu._lib.UnsupportedShape):   # 48 channels: not a matrix-core K multiple this kernel instantiates
-        lgu.ops.lowmem_pyramid_forward_mixed(torch.zeros(B, H, W, 48, device="cuda").half(),
-                                             [torch.zeros(B, f.shape[1], f.shape[2], 48, device="cuda").half() for f in f2s],
+        lgu.ops.lowmem_pyramid_forward_mixed(cast(torch.zeros(B, H, W, 48, device="cuda")),
+                                             [cast(torch.zeros(B, f.shape[1], f.shape[2], 48, device="cuda")) for f in f2s],
                                              coords, offs_a, radius)

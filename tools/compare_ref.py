@@ -106,7 +106,7 @@ def main():
     ys, xs = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing="ij")
     base = torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, device=dev)
     off0 = (4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device=dev))).contiguous()
-    tot_ref = tot_our = tot_old = tot_mixed = tot_mixed_valu = worst_mixed = 0.0
+    tot_ref = tot_our = tot_old = tot_valu = tot_mixed = tot_mixed_valu = worst_mixed = 0.0
     per_level = []
     per_level_mixed = []
     f1h = f1.half()
@@ -133,6 +133,8 @@ def main():
         worst_mixed = max(worst_mixed, float((m_ - r_).abs().max()))
         os.environ["LGU_LOWMEM_VARIANT"] = "1"
         tot_old += timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
+        os.environ["LGU_LOWMEM_VARIANT"] = "2"
+        tot_valu += timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
         os.environ.pop("LGU_LOWMEM_VARIANT")
         if l == 1:
             a, = alt.altcorr_forward(f1, f2, cl, 1)
@@ -141,7 +143,7 @@ def main():
                               "ref_ms": timeit(lambda: alt.altcorr_forward(f1, f2, cl, 1), iters=5, warm=1),
                               "ours_ms": timeit(lambda: ops.altcorr_forward(f1, f2, cl, 1), iters=5, warm=1)}))
     print(json.dumps({"op": "lowMem_defSample 4 levels B=16 60x80 C=128", "max_abs_diff_vs_reference": worst,
-                      "ref_ms": tot_ref, "ours_ms": tot_our, "ours_wave_per_pixel_ms": tot_old, "ours_ms_per_level": per_level, "ours_half_features_ms": tot_mixed, "ours_half_features_valu_kernel_ms": tot_mixed_valu, "half_features_max_abs_diff_vs_reference_on_float_copies": worst_mixed, "ours_half_features_Mpix_edges_per_s": B * H * W / tot_mixed / 1e3, "ours_half_features_ms_per_level": per_level_mixed, "speedup": tot_ref / tot_our,
+                      "ref_ms": tot_ref, "ours_ms": tot_our, "ours_wave_per_pixel_ms": tot_old, "ours_valu_tile_kernel_ms": tot_valu, "ours_ms_per_level": per_level, "ours_half_features_ms": tot_mixed, "ours_half_features_valu_kernel_ms": tot_mixed_valu, "half_features_max_abs_diff_vs_reference_on_float_copies": worst_mixed, "ours_half_features_Mpix_edges_per_s": B * H * W / tot_mixed / 1e3, "ours_half_features_ms_per_level": per_level_mixed, "speedup": tot_ref / tot_our,
                       "ours_Mpix_edges_per_s": B * H * W / tot_our / 1e3}))
 
 

@@ -24,6 +24,10 @@ for l in range(4):
     f1h, f2h = f1.half(), f2.half()
     for _ in range(3):
         ops.lowMem_defSample(f1, f2, cl, off0 if l < 2 else zero, 3)
+    os.environ["LGU_LOWMEM_VARIANT"] = "2"
+    for _ in range(3):
+        ops.lowMem_defSample(f1, f2, cl, off0 if l < 2 else zero, 3)
+    os.environ.pop("LGU_LOWMEM_VARIANT")
     for _ in range(5):
         ops.lowMem_defSample_mixed(f1h, f2h, cl, off0 if l < 2 else zero, 3)
 torch.cuda.synchronize()
