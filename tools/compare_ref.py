@@ -97,7 +97,30 @@ def main():
     print(json.dumps({"op": "volume post-processing (mask + /den + corr + 3 pools) E=8",
                       "max_abs_diff_vs_reference": max(float((a_.reshape(-1) - b_.reshape(-1)).abs().max()) for a_, b_ in zip(r_, o_)),
                       "ref_ms": timeit(ref_post), "ours_ms": timeit(lambda: ops.volume_pyramid(means, covs, vg, 4, 4))}))
-    del vols, vg, a, b, r_, o_
+    # backward operators (training path), 4 edges of BASELINE config 2
+    Eb = 4
+    vb = [v[:Eb].contiguous() for v in vols[:2]]
+    cb0, cb1 = lvl_coords[0][:Eb].contiguous(), lvl_coords[1][:Eb].contiguous()
+    ob = ref_offs[0][:Eb].contiguous()
+    g49 = torch.randn(Eb, 7, 7, H1, W1, device=dev)
+    g9 = torch.randn(Eb, 3, 3, H1, W1, device=dev)
+    ra = ref.defCorr_index_backward(vb[0], cb0, ob.clone(), g49, R)
+    oa = ops.defCorr_index_backward(vb[0], cb0, ob.clone(), g49, R)
+    print(json.dumps({"op": "defCorr_index_backward level0 E=4", "max_abs_diff_vs_reference": max(float((x - y).abs().max()) for x, y in zip(ra, oa)),
+                      "ref_ms": timeit(lambda: ref.defCorr_index_backward(vb[0], cb0, ob, g49, R), iters=10, warm=2),
+                      "ours_ms": timeit(lambda: ops.defCorr_index_backward(vb[0], cb0, ob, g49, R), iters=10, warm=2)}))
+    ra = ref.corr_index_backward(vb[1], cb1, g9, 1)
+    oa = ops.corr_index_backward(vb[1], cb1, g9, 1)
+    print(json.dumps({"op": "corr_index_backward r=1 level1 E=4", "max_abs_diff_vs_reference": float((ra[0] - oa[0]).abs().max()),
+                      "ref_ms": timeit(lambda: ref.corr_index_backward(vb[1], cb1, g9, 1), iters=10, warm=2),
+                      "ours_ms": timeit(lambda: ops.corr_index_backward(vb[1], cb1, g9, 1), iters=10, warm=2)}))
+    gv = torch.randn_like(vg[:Eb])
+    ra = ref.gaussianMask_backward(means[:Eb].contiguous(), covs[:Eb].contiguous(), vg[:Eb].contiguous(), gv, 4)
+    oa = ops.gaussianMask_backward(means[:Eb].contiguous(), covs[:Eb].contiguous(), vg[:Eb].contiguous(), gv, 4)
+    print(json.dumps({"op": "gaussianMask_backward E=4", "max_rel_diff_vs_reference": max(float(((x - y).abs() / (y.abs() + 1e-3)).max()) for x, y in zip(oa, ra)),
+                      "ref_ms": timeit(lambda: ref.gaussianMask_backward(means[:Eb].contiguous(), covs[:Eb].contiguous(), vg[:Eb].contiguous(), gv, 4), iters=10, warm=2),
+                      "ours_ms": timeit(lambda: ops.gaussianMask_backward(means[:Eb].contiguous(), covs[:Eb].contiguous(), vg[:Eb].contiguous(), gv, 4), iters=10, warm=2)}))
+    del vols, vg, a, b, r_, o_, vb, gv, ra, oa
     torch.cuda.empty_cache()
 
     # low-memory path, BASELINE config 4 shapes: 60x80 fmaps (needs H%4==0, W%8==0), C=128, B=16 edges
@@ -137,6 +160,12 @@ def main():
         tot_valu += timeit(lambda: ops.lowMem_defSample(f1, f2, cl, off0, 3), iters=5, warm=1)
         os.environ.pop("LGU_LOWMEM_VARIANT")
         if l == 1:
+            ga = torch.randn(B, 1, 9, H, W, device=dev)
+            rb = alt.altcorr_backward(f1, f2, cl, ga, 1)
+            ob_ = ops.altcorr_backward(f1, f2, cl, ga, 1)
+            print(json.dumps({"op": "altcorr_backward r=1 level1 B=16 60x80", "max_abs_diff_vs_reference": max(float((x - y).abs().max()) for x, y in zip(rb[:2], ob_[:2])),
+                              "ref_ms": timeit(lambda: alt.altcorr_backward(f1, f2, cl, ga, 1), iters=5, warm=1),
+                              "ours_ms": timeit(lambda: ops.altcorr_backward(f1, f2, cl, ga, 1), iters=5, warm=1)}))
             a, = alt.altcorr_forward(f1, f2, cl, 1)
             b, = ops.altcorr_forward(f1, f2, cl, 1)
             print(json.dumps({"op": "altcorr r=1 level1 B=16 60x80", "max_abs_diff_vs_reference": float((a - b).abs().max()),
