@@ -104,6 +104,10 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
  *   Served for radius 3 (the production case); otherwise LGU_E_UNSUPPORTED.  Results are bit-identical to the
  *   reference layout. */
 #define LGU_PYR_TILED 2
+/* LGU_PYR_COORDS_LAST: coords is (E,H1,W1,2) with x, y interleaved — how factor_graph.py holds them — instead of the
+ *   operator's (E,2,H1,W1) planes: saves the permute().contiguous() pass of corr.py:91 in front of every lookup.
+ *   Served by the fast kernels (radius 1..3, 16-byte aligned operands); otherwise LGU_E_UNSUPPORTED. */
+#define LGU_PYR_COORDS_LAST 4
 int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords,
                                 float* const* offsets, float* out,
                                 int L, int E, int H1, int W1, const int* H2, const int* W2,

@@ -145,11 +145,13 @@ class CorrBlock:
         batch, num, ht, wd, _ = coords.shape
         E = batch * num
         rd = 2 * self.radius + 1
-        coords = coords.permute(0, 1, 4, 2, 3).contiguous().view(E, 2, ht, wd)
+        coords_xy = coords.reshape(E, ht, wd, 2)   # as handed over: x, y interleaved (the fused kernel reads this form)
+        coords = None                               # (E,2,ht,wd) planes, made only where an operator needs them
 
         needs_grad = torch.is_grad_enabled() and (
             any(v.requires_grad for v in self.corr_pyramid) or any(o.requires_grad for o in self.offset))
         if needs_grad:
+            coords = coords_xy.permute(0, 3, 1, 2).contiguous()
             # training: reference-shaped composition through the autograd Functions.
             # Uncertainty probe on level 1; the mask is folded into offset[1] and PERSISTS
             # across calls, exactly like the reference (corr.py:94-99)
@@ -178,13 +180,14 @@ class CorrBlock:
         try:
             if getattr(self, "_plan_key", None) != key:
                 self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True, tiled=self._tiled,
-                                                    level_hw=self._level_hw)
+                                                    level_hw=self._level_hw, coords_last=True)
                 self._plan_key = key
-            out = self._plan(coords)
+            out = self._plan(coords_xy if coords_xy.is_contiguous() else coords_xy.contiguous())
         except _lib.UnsupportedShape:
             # shapes the fused probe does not serve (e.g. W2 % 4 != 0): separate probe ops
             self._plan_key = None
             self._to_reference_layout()
+            coords = coords_xy.permute(0, 3, 1, 2).contiguous()
             pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
             probe, = ops.corr_index_forward(pyr[1], (coords / 2).contiguous(), 1)
             self.offset[1] = (self.offset[1] * _uncertainty_mask(probe)).contiguous()

@@ -452,8 +452,14 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
   for (int k = 0; k < GP; k++) {
     const int px = xbase + w * GP + k;
     const bool pv = px < p.W1;
-    x0[k] = pv ? p.coords[((size_t)e * 2 + 0) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
-    y0[k] = pv ? p.coords[((size_t)e * 2 + 1) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
+    if (p.flags & LGU_PYR_COORDS_LAST) {  // (E,H1,W1,2): x, y interleaved, as the SLAM system holds them
+      const float2 c = pv ? reinterpret_cast<const float2*>(p.coords)[(size_t)e * HW1 + (size_t)y * p.W1 + px] : make_float2(0.f, 0.f);
+      x0[k] = c.x;
+      y0[k] = c.y;
+    } else {
+      x0[k] = pv ? p.coords[((size_t)e * 2 + 0) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
+      y0[k] = pv ? p.coords[((size_t)e * 2 + 1) * HW1 + (size_t)y * p.W1 + px] : 0.0f;
+    }
 #pragma unroll
     for (int l = 0; l < FASTL; l++) {
       off[k][l] = make_float2(0.0f, 0.0f);
@@ -734,6 +740,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     if (!volumes[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
   const bool probe = (flags & LGU_PYR_PROBE) != 0;
   const bool tiled = (flags & LGU_PYR_TILED) != 0;
+  const bool coords_last = (flags & LGU_PYR_COORDS_LAST) != 0;
   if (probe && (L < 2 || offsets[1] == nullptr)) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -773,6 +780,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       fast = fast && (tiled || W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
     // the tiled layout is served by the production gather kernel at radius 3 only (what CorrBlock builds)
     if (tiled && !(fast && radius == 3 && (variant == 0 || variant == 4 || variant == 5))) return LGU_E_UNSUPPORTED;
+    // interleaved coords are read by the register-gather kernels only
+    if (coords_last && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {

@@ -273,7 +273,7 @@ def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=Non
         return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius)(coords, out=out)
 
 
-PYR_PROBE, PYR_TILED = 1, 2  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)
+PYR_PROBE, PYR_TILED, PYR_COORDS_LAST = 1, 2, 4  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)
 TILE_H, TILE_W = 4, 8        # tiled slice layout: 4 x 8 element tiles, one 128-byte line each
 
 
@@ -316,7 +316,8 @@ def _level_dims(volumes, tiled, level_hw):
     return [h for h, _ in level_hw], [w for _, w in level_hw]
 
 
-def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None, tiled=False, level_hw=None):
+def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None, tiled=False, level_hw=None,
+                            coords_last=False):
     """Fused CorrBlock.__call__ body (reference droid_slam/modules/corr.py:88-109): all
     pyramid levels in ONE launch, written straight into the concatenated tensor.
 
@@ -325,6 +326,7 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     or None for a structurally-zero level.  Offsets are modified in place (centre zeroing).
     tiled=True: volumes are in the tiled slice layout (volume_retile / volume_pyramid(tiled=True));
     level_hw = their logical (H2, W2) when padded.  Same results, fewer HBM lines touched.
+    coords_last=True: coords is (E,H1,W1,2), x and y interleaved (no permute pass in front of the lookup).
     Returns (E, L*rd*rd, H1, W1).
     """
     L = len(volumes)
@@ -348,7 +350,9 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
     h2 = (ctypes.c_int * L)(*hs)
     w2 = (ctypes.c_int * L)(*ws)
-    flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0)
+    flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
+    if tuple(coords.shape) != ((E, H1, W1, 2) if coords_last else (E, 2, H1, W1)):
+        raise RuntimeError("defcorr_pyramid_forward: coords must be %s" % ("(E,H1,W1,2)" if coords_last else "(E,2,H1,W1)"))
     with torch.cuda.device(coords.device):
         rc = _lib.load().lgu_defcorr_pyramid_fwd_f32(vp, _ptr(coords), op, _ptr(out), L, E, H1, W1, h2, w2, radius,
                                                      flags, _stream(coords))
@@ -391,7 +395,8 @@ class DefcorrPyramidPlan:
     every update) and by bench.py so the step is not bound by Python argument handling.
     """
 
-    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None):
+    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False):
+        """coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1)."""
         L = len(volumes)
         if len(offsets) != L:
             raise RuntimeError("DefcorrPyramidPlan: need one offset entry (tensor or None) per level")
@@ -402,7 +407,9 @@ class DefcorrPyramidPlan:
                 named += [offsets[l], "offset[%d]" % l]
         _check(*named)
         self._keep = (list(volumes), list(offsets))  # keep the buffers alive
-        self.L, self.radius, self.flags = L, radius, (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0)
+        self.L, self.radius = L, radius
+        self.flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
+        self.coords_last = coords_last
         self.E, self.H1, self.W1 = volumes[0].shape[:3]
         self.device = volumes[0].device
         self.channels = L * (2 * radius + 1) ** 2
@@ -414,8 +421,9 @@ class DefcorrPyramidPlan:
         self._fn = _lib.load().lgu_defcorr_pyramid_fwd_f32
 
     def __call__(self, coords, out=None):
-        if tuple(coords.shape) != (self.E, 2, self.H1, self.W1):
-            raise RuntimeError("coords must be (E,2,H1,W1)")
+        want = (self.E, self.H1, self.W1, 2) if self.coords_last else (self.E, 2, self.H1, self.W1)
+        if tuple(coords.shape) != want:
+            raise RuntimeError("coords must be %s" % ("(E,H1,W1,2)" if self.coords_last else "(E,2,H1,W1)"))
         _check(coords, "coords")
         if out is None:
             out = torch.empty((self.E, self.channels, self.H1, self.W1), dtype=torch.float32, device=self.device)

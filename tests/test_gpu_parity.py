@@ -823,3 +823,29 @@ def test_lowmem_pyramid_fused_launch_equals_per_level_operators(lgu, oracle, cfg
         lgu.ops.lowmem_pyramid_forward_mixed(cast(torch.zeros(B, H, W, 48, device="cuda")),
                                              [cast(torch.zeros(B, f.shape[1], f.shape[2], 48, device="cuda")) for f in f2s],
                                              coords, offs_a, radius)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("probe", [False, True])
+def test_interleaved_coords_equal_planar_coords(lgu, tiled, probe):
+    """LGU_PYR_COORDS_LAST: coords as (E,H1,W1,2) (how the factor graph holds them) == the operator's (E,2,H1,W1)
+    planes, bit for bit; kernels that do not read the interleaved form say so."""
+    case = inputs.pyramid_case(61, 2, 48, 64, 4, 3, 3.0, 4.0, False)
+    vols = [dev(v) for v in case["volumes"]]
+    hw = [tuple(v.shape[3:]) for v in vols]
+    if tiled:
+        vols = [lgu.ops.volume_retile(v) for v in vols]
+    coords = dev(case["coords"])
+    coords_xy = coords.permute(0, 2, 3, 1).contiguous()
+    oa = [dev(o) if o is not None else None for o in case["offsets"]]
+    ob = [dev(o) if o is not None else None for o in case["offsets"]]
+    a = lgu.ops.defcorr_pyramid_forward(vols, coords, oa, 3, probe=probe, tiled=tiled, level_hw=hw if tiled else None)
+    b = lgu.ops.defcorr_pyramid_forward(vols, coords_xy, ob, 3, probe=probe, tiled=tiled, level_hw=hw if tiled else None, coords_last=True)
+    assert torch.equal(a, b) and all(x is None or torch.equal(x, y) for x, y in zip(oa, ob))
+    plan = lgu.ops.DefcorrPyramidPlan(vols, ob, 3, probe=False, tiled=tiled, level_hw=hw if tiled else None, coords_last=True)
+    with pytest.raises(RuntimeError, match="coords must be"):
+        plan(coords)
+    if not tiled:
+        set_variant(2)   # the generic kernel reads planes only
+        with pytest.raises(lgu._lib.UnsupportedShape):
+            lgu.ops.defcorr_pyramid_forward(vols, coords_xy, ob, 3, coords_last=True)
