@@ -260,7 +260,8 @@ class AltCorrBlock:
         self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
 
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
-        # operators accumulate in fp32 and equal the reference's `.float()` call sites bit for bit.
+        # operators take exact half products, accumulate in fp32 and equal the reference's `.float()`
+        # call sites up to fp32 summation order (<= 1e-5).
         mixed = f1.dtype == torch.float16
         f1 = f1.contiguous() if mixed else f1.float().contiguous()
         if S == 1 and B == 1 and self.num_levels >= 2:
