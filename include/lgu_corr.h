@@ -181,26 +181,27 @@ int lgu_altcorr_fwd_h16(const void* fmap1_half, const void* fmap2_half, const fl
                         int B, int S, int H1, int W1, int H2, int W2, int C,
                         int radius, void* stream);
 
-/* The per-level loop of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:192-213) in ONE launch, for
- * half feature maps: for l in 0..L-1   out[:, :, l*rd*rd:(l+1)*rd*rd] =
- *     lowMem_defSample(fmap1.float(), fmap2[l].float(), coords / 2^l, offsets[l], radius)
+/* The per-level loop of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:192-213) in ONE launch:
+ *   for l in 0..L-1   out[:, :, l*rd*rd:(l+1)*rd*rd] =
+ *       lowMem_defSample(fmap1[ii].float(), fmap2[l][jj].float(), coords / 2^(lbase+l), offsets[l], radius)
  * written straight into the concatenated tensor out (B,S,L*rd*rd,H1,W1) (what corr.py:211-213 builds for S == 1).
- * fmap2[l] (B,H2[l],W2[l],C) half; coords (B,S,H1,W1,2) in level-0 units; offsets[l] (NO,H1,W1,rd,rd,2) IN/OUT with the
- * reference's offset[b*s] indexing, or NULL = zero offsets for that level.  `fmap2`, `offsets`, `H2`, `W2` are HOST
- * arrays of length L <= 4.  The level-1 uncertainty probe of corr.py:201-206 stays a separate call
- * (lgu_altcorr_fwd_h16) whose mask the caller folds into offsets[1] first.  Requires C in {32,64,128,256} and
- * radius in 1..3, otherwise LGU_E_UNSUPPORTED (compose the per-level entries instead). */
+ *   fmap1 (F,H1,W1,C), fmap2[l] (F,H2[l],W2[l],C): the FRAME buffers of the pyramid; ii, jj: device arrays of B int64
+ *   frame indices (corr.py:193-194 `self.pyramid[i][:, jj]`) read in place — no gathered per-edge copies.  ii == jj ==
+ *   NULL: fmap1 / fmap2[l] are already per-edge, (B,...).
+ *   coords (B,S,H1,W1,2) in level-0 units; lbase = pyramid level of fmap2[0] (the level-1 probe of corr.py:201-202 is
+ *   this entry with L = 1, lbase = 1, offsets = {NULL}, radius = 1).
+ *   offsets[l] (NO,H1,W1,rd,rd,2) IN/OUT with the reference's offset[b*s] indexing, or NULL = zero offsets.
+ *   `fmap2`, `offsets`, `H2`, `W2` are HOST arrays of length L <= 4.
+ * _h16: half feature maps (C in {32,64,128,256}); _f32: float feature maps, exact fp32 on v_mfma_f32_16x16x4_f32
+ * (C in {16,32,64,128}); radius in 1..3; otherwise LGU_E_UNSUPPORTED (compose the per-level entries instead). */
 int lgu_lowmem_pyramid_fwd_h16(const void* fmap1_half, const void* const* fmap2_half, const float* coords,
                                float* const* offsets, float* out,
-                               int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                               int radius, void* stream);
-
-/* The same for float feature maps (exact fp32 products and sums on v_mfma_f32_16x16x4_f32);
- * requires C in {16, 32, 64, 128}. */
+                               int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, const long long* ii, const long long* jj, void* stream);
 int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords,
                                float* const* offsets, float* out,
-                               int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                               int radius, void* stream);
+                               int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                               int radius, const long long* ii, const long long* jj, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,10 +30,10 @@ SIGNATURES = {
     "lgu_altcorr_fwd_f32": [_vp] * 4 + [_int] * 8 + [_vp],
     "lgu_lowmem_defsample_fwd_h16": [_vp] * 5 + [_int] * 9 + [_vp],
     "lgu_altcorr_fwd_h16": [_vp] * 4 + [_int] * 8 + [_vp],
-    "lgu_lowmem_pyramid_fwd_h16": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int,
-                                   ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp],
-    "lgu_lowmem_pyramid_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int,
-                                   ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp],
+    "lgu_lowmem_pyramid_fwd_h16": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
+                                   ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
+    "lgu_lowmem_pyramid_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
+                                   ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
     "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],
 }
 

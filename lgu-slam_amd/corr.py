@@ -264,22 +264,25 @@ class AltCorrBlock:
         # call sites up to fp32 summation order (<= 1e-5).
         mixed = f1.dtype == torch.float16
         f1 = f1.contiguous() if mixed else f1.float().contiguous()
-        if S == 1 and B == 1 and self.num_levels >= 2:
-            # one sample per pixel (the SLAM system's case): the level-1 probe, then ALL levels in one launch
-            # written straight into the concatenated tensor (ops.LowmemPyramidPlan); levels whose offsets are
-            # zero by construction read no offset tensor at all.  Half feature buffers stay half.
+        if S == 1 and B == 1 and self.num_levels >= 2 and ii.dtype == torch.int64 and jj.dtype == torch.int64:
+            # one sample per pixel (the SLAM system's case): the level-1 probe and then ALL levels in one launch each,
+            # written straight into the concatenated tensor (ops.LowmemPyramidPlan).  Both read the frame buffers in
+            # place at ii / jj (no per-edge gathers of the pyramid), half buffers stay half, and levels whose offsets
+            # are zero by construction read no offset tensor at all.
             try:
-                f2s = [self.pyramid[i][:, jj].reshape((B * N,) + self.pyramid[i].shape[2:]) for i in range(self.num_levels)]
-                f2s = [f.contiguous() if mixed else f.float().contiguous() for f in f2s]
+                frames = [p_[0].contiguous() for p_ in self.pyramid]            # (N,Hl,Wl,C): views of the stored pyramid
+                if not mixed:
+                    frames = [f.float() for f in frames]
+                iic, jjc = ii.contiguous(), jj.contiguous()
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
-                probe, = (ops.altcorr_forward_mixed if mixed else ops.altcorr_forward)(f1, f2s[1], (c0 / 2).contiguous(), 1)
+                probe = ops.lowmem_pyramid_forward_mixed(frames[0], [frames[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1)
                 probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
                 mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
                 self.offset[1] = self.offset[1] * mask
                 offs = [None if zero_level[i] else self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
                         for i in range(self.num_levels)]
-                fused = ops.lowmem_pyramid_forward_mixed(f1, f2s, c0, offs, self.radius)  # (E,1,L*rd*rd,H,W)
-                return fused.view(B, N, -1, H, W).unsqueeze(-1)
+                fused = ops.lowmem_pyramid_forward_mixed(frames[0], frames, c0, offs, self.radius, ii=iic, jj=jjc)
+                return fused.view(B, N, -1, H, W).unsqueeze(-1)   # (1,E,L*rd*rd,H,W,S=1)
             except _lib.UnsupportedShape:
                 # channel counts / radii the matrix-core kernel does not serve: per-level operators below
                 self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)

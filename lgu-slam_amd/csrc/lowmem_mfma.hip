@@ -127,6 +127,9 @@ struct MmParams {
   float* corr;
   int H2[MM_MAXL], W2[MM_MAXL];
   int L, B, S, H1, W1, blocks_x, blocks_y, xcd_map, vec_out;
+  int lbase;             // pyramid level of fmap2[0]: level l of the launch samples at coords / 2^(lbase + l)
+  const long long* ii;   // optional frame indices (device, int64): edge b reads fmap1[ii[b]] and fmap2[l][jj[b]]
+  const long long* jj;   // straight from the frame buffers — no gathered per-edge copies; null = fmap*[b]
 };
 
 // One wave = one workgroup = one 4 x 4 pixel block.  Lane layout outside the sweep: row = lane / 16 is a
@@ -170,12 +173,13 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
 #pragma unroll
   for (int l = 1; l < MM_MAXL; l++)
     if (lvl == l) { fmap2 = static_cast<const T*>(p.fmap2[l]); offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
-  const float cscale = __builtin_ldexpf(1.0f, -lvl);  // coords / 2^l (corr.py:197): exact in fp32
+  const float cscale = __builtin_ldexpf(1.0f, -(p.lbase + lvl));  // coords / 2^l (corr.py:197): exact in fp32
   const int n = blockIdx.y;
   const int by = blk / blocks_x, bx = blk % blocks_x;
   const size_t HW1 = (size_t)H1 * W1;
-  const T* const F1 = static_cast<const T*>(p.fmap1) + (size_t)b * HW1 * C;
-  const T* const F2 = fmap2 + (size_t)b * H2 * W2 * C;
+  const size_t f1i = p.ii ? (size_t)p.ii[b] : (size_t)b, f2i = p.jj ? (size_t)p.jj[b] : (size_t)b;  // wave-uniform
+  const T* const F1 = static_cast<const T*>(p.fmap1) + f1i * HW1 * C;
+  const T* const F2 = fmap2 + f2i * H2 * W2 * C;
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets (altcorr)
   float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
   const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
@@ -471,12 +475,13 @@ int lowmem_mfma_dispatch_f32(const float* fmap1, const float* fmap2, const float
 extern "C" {
 
 static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
-                         float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                         int radius, void* stream) {
+                         float* out, int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                         int radius, const long long* ii, const long long* jj, void* stream) {
   using namespace lgu;
   if (!fmap1 || !fmap2 || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
-  if (L < 1 || L > MM_MAXL || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0) return LGU_E_BADARG;
-  if ((long long)(B - 1) * (S - 1) >= (long long)NO) return LGU_E_BADARG;
+  if (L < 1 || L > MM_MAXL || lbase < 0 || lbase > 16 || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0)
+    return LGU_E_BADARG;
+  if ((long long)(B - 1) * (S - 1) >= (long long)NO || (ii == nullptr) != (jj == nullptr)) return LGU_E_BADARG;
   MmParams p = {};
   p.fmap1 = fmap1;
   for (int l = 0; l < L; l++) {
@@ -487,6 +492,7 @@ static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2,
   }
   p.coords = coords; p.corr = out;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
+  p.lbase = lbase; p.ii = ii; p.jj = jj;
   if (B == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rc = half ? mfma_dispatch<_Float16>(p, C, radius, st) : mfma_dispatch<float>(p, C, radius, st);
@@ -494,16 +500,16 @@ static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2,
 }
 
 int lgu_lowmem_pyramid_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
-                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                               int radius, void* stream) {
-  return pyramid_entry(true, fmap1, fmap2, coords, offsets, out, L, B, S, H1, W1, H2, W2, C, NO, radius, stream);
+                               float* out, int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C,
+                               int NO, int radius, const long long* ii, const long long* jj, void* stream) {
+  return pyramid_entry(true, fmap1, fmap2, coords, offsets, out, L, lbase, B, S, H1, W1, H2, W2, C, NO, radius, ii, jj, stream);
 }
 
 int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords, float* const* offsets,
-                               float* out, int L, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                               int radius, void* stream) {
-  return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, B, S, H1, W1, H2,
-                       W2, C, NO, radius, stream);
+                               float* out, int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C,
+                               int NO, int radius, const long long* ii, const long long* jj, void* stream) {
+  return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, lbase, B, S, H1, W1,
+                       H2, W2, C, NO, radius, ii, jj, stream);
 }
 
 }  // extern "C"

@@ -225,12 +225,17 @@ def altcorr_forward_mixed(fmap1, fmap2, coords, radius):
 
 class LowmemPyramidPlan:
     """The per-level loop of AltCorrBlock.corr_fn (reference corr.py:192-213) as ONE launch over half or float
-    feature maps (lgu_lowmem_pyramid_fwd_h16 / _f32): level l samples fmap2s[l] at coords / 2^l with offsets[l] (None = zero
-    offsets) and writes channels l*rd*rd.. of the concatenated output (B, S, L*rd*rd, H1, W1).  The pointer
-    tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first call)
-    for channel counts / radii the matrix-core kernel does not serve."""
+    feature maps (lgu_lowmem_pyramid_fwd_h16 / _f32): level l samples fmap2s[l] at coords / 2^(lbase+l) with
+    offsets[l] (None = zero offsets) and writes channels l*rd*rd.. of the concatenated output
+    (B, S, L*rd*rd, H1, W1).
 
-    def __init__(self, fmap1, fmap2s, offsets, radius):
+    Two forms.  Per-edge maps: fmap1 (B,H1,W1,C), fmap2s[l] (B,H2l,W2l,C).  Frame buffers + indices (ii, jj int64
+    device tensors of length B): fmap1 (F,H1,W1,C), fmap2s[l] (F,H2l,W2l,C) are read in place at frames ii[b] /
+    jj[b] — what `self.pyramid[i][:, jj]` gathers in the reference, without the per-edge copies.
+    The pointer tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first
+    call) for channel counts / radii the matrix-core kernel does not serve."""
+
+    def __init__(self, fmap1, fmap2s, offsets, radius, ii=None, jj=None, lbase=0):
         L = len(fmap2s)
         if len(offsets) != L or not 1 <= L <= 4:
             raise RuntimeError("LowmemPyramidPlan: need 1..4 levels and one offset entry (tensor or None) per level")
@@ -240,15 +245,24 @@ class LowmemPyramidPlan:
             _check_dtype(f, "fmap2[%d]" % l, dt)
             if offsets[l] is not None:
                 _check(offsets[l], "offset[%d]" % l)
-        self._keep = (fmap1, list(fmap2s), list(offsets))
-        self.L, self.radius = L, radius
-        self.B, self.H1, self.W1, self.C = fmap1.shape
+        if (ii is None) != (jj is None):
+            raise RuntimeError("LowmemPyramidPlan: pass both ii and jj or neither")
+        if ii is not None:
+            _check_dtype(ii, "ii", torch.int64); _check_dtype(jj, "jj", torch.int64)
+            if ii.dim() != 1 or ii.shape != jj.shape:
+                raise RuntimeError("LowmemPyramidPlan: ii and jj must be 1-D and of equal length")
+        self._keep = (fmap1, list(fmap2s), list(offsets), ii, jj)
+        self.L, self.radius, self.lbase = L, radius, lbase
+        _, self.H1, self.W1, self.C = fmap1.shape
+        self.B = fmap1.shape[0] if ii is None else ii.shape[0]
         self.device = fmap1.device
-        self.NO = max([o.shape[0] for o in offsets if o is not None] or [self.B])
+        self.NO = max([o.shape[0] for o in offsets if o is not None] or [max(self.B, 1)])
         self._f2 = (_vp * L)(*[f.data_ptr() for f in fmap2s])
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
         self._h2 = (ctypes.c_int * L)(*[f.shape[1] for f in fmap2s])
         self._w2 = (ctypes.c_int * L)(*[f.shape[2] for f in fmap2s])
+        self._ii = ii.data_ptr() if ii is not None and self.B else None
+        self._jj = jj.data_ptr() if jj is not None and self.B else None
         self._fn = _lib.load().lgu_lowmem_pyramid_fwd_h16 if dt == torch.float16 else _lib.load().lgu_lowmem_pyramid_fwd_f32
 
     def __call__(self, coords, out=None):
@@ -261,16 +275,17 @@ class LowmemPyramidPlan:
             out = torch.empty((B, S, ch, H1, W1), dtype=torch.float32, device=self.device)
         if B == 0:
             return out
-        rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, B, S, H1, W1,
-                      self._h2, self._w2, self.C, self.NO, self.radius, torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B, S,
+                      H1, W1, self._h2, self._w2, self.C, self.NO, self.radius, self._ii, self._jj,
+                      torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "lowmem_pyramid_forward")
         return out
 
 
-def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None):
+def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None, ii=None, jj=None, lbase=0):
     """One-shot form of LowmemPyramidPlan (half or float feature maps)."""
     with torch.cuda.device(fmap1.device):
-        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius)(coords, out=out)
+        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius, ii=ii, jj=jj, lbase=lbase)(coords, out=out)
 
 
 PYR_PROBE, PYR_TILED, PYR_COORDS_LAST = 1, 2, 4  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)

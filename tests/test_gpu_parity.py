@@ -849,3 +849,30 @@ def test_interleaved_coords_equal_planar_coords(lgu, tiled, probe):
         set_variant(2)   # the generic kernel reads planes only
         with pytest.raises(lgu._lib.UnsupportedShape):
             lgu.ops.defcorr_pyramid_forward(vols, coords_xy, ob, 3, coords_last=True)
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_lowmem_pyramid_reads_frame_buffers_in_place(lgu, half):
+    """ii / jj form of the fused low-memory launch: the frame buffers are indexed inside the kernel (what
+    `self.pyramid[i][:, jj]` gathers in reference corr.py:193-194) == the launch over gathered per-edge copies,
+    BIT FOR BIT; lbase shifts the coordinate scale (the level-1 probe is L = 1, lbase = 1, radius 1, no offsets)."""
+    torch.manual_seed(21)
+    F_, H, W, C, L = 5, 24, 32, 128, 3
+    cast = (lambda t: t.half()) if half else (lambda t: t)
+    frames = [cast(torch.randn(F_, H >> l, W >> l, C, device="cuda") * 0.125) for l in range(L)]
+    ii = torch.tensor([0, 0, 1, 4, 3, 2, 2, 4, 1], device="cuda")
+    jj = torch.tensor([1, 2, 3, 0, 2, 4, 0, 4, 0], device="cuda")
+    E = ii.numel()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(E, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = (4 * torch.tanh(torch.randn(E, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    oa, ob = [o0.clone(), None, None], [o0.clone(), None, None]
+    got = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], frames, coords, oa, 3, ii=ii, jj=jj)
+    want = lgu.ops.lowmem_pyramid_forward_mixed(frames[0][ii].contiguous(), [f[jj].contiguous() for f in frames], coords, ob, 3)
+    assert torch.equal(got, want) and torch.equal(oa[0], ob[0])
+    probe = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], [frames[1]], coords, [None], 1, ii=ii, jj=jj, lbase=1)
+    alt = (lgu.ops.altcorr_forward_mixed if half else lgu.ops.altcorr_forward)(frames[0][ii].contiguous(), frames[1][jj].contiguous(),
+                                                                              (coords / 2).contiguous(), 1)[0]
+    assert torch.equal(probe, alt)
+    with pytest.raises(RuntimeError, match="both ii and jj"):
+        lgu.ops.LowmemPyramidPlan(frames[0], frames, oa, 3, ii=ii)
