@@ -113,6 +113,16 @@ int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords
                                 int L, int E, int H1, int W1, const int* H2, const int* W2,
                                 int radius, int flags, void* stream);
 
+/* The same with a storage indirection for the volumes: edge e's slices are at slot edge_slot[e] (device array of E
+ * int32) of the level buffers, which may hold more slots than E.  This is what lets the CorrBlock state container
+ * implement `cat` (factor_graph.py:123) and `__getitem__` (:139) by editing a small index array instead of copying the
+ * multi-GB pyramid as the reference's tensor concatenation / boolean indexing do.  Offsets, coords and out are indexed by e as before.
+ * Served by the fast kernels; otherwise LGU_E_UNSUPPORTED. */
+int lgu_defcorr_pyramid_slots_fwd_f32(const float* const* volumes, const int* edge_slot, const float* coords,
+                                      float* const* offsets, float* out,
+                                      int L, int E, int H1, int W1, const int* H2, const int* W2,
+                                      int radius, int flags, void* stream);
+
 /* Fused volume post-processing of CorrBlock.__init__ (reference droid_slam/gaussianMask_cuda.py:84-86
  * and droid_slam/modules/corr.py:79-86): in ONE pass over the raw all-pairs volume
  *   level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(covs.x*covs.y)) + volume

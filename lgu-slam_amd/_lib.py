@@ -23,6 +23,8 @@ SIGNATURES = {
     "lgu_gaussmask_bwd_f32": [_vp] * 6 + [_int] * 6 + [_vp],
     "lgu_defcorr_pyramid_fwd_f32": [ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int,
                                     ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _vp],
+    "lgu_defcorr_pyramid_slots_fwd_f32": [ctypes.POINTER(_vp), _vp, _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int,
+                                          ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _vp],
     "lgu_volume_pyramid_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_pyramid_tiled_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_retile_f32": [_vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp],

@@ -115,7 +115,8 @@ class CorrBlock:
 
         self.t = feats.permute(0, 2, 3, 1).contiguous()
         needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(q.requires_grad for q in GA.parameters()))
-        self.corr_pyramid = None
+        self._store = None       # slot-indirected level buffers (inference), see _adopt_store
+        self._pyr = None         # plain list of level tensors in edge order (training / fallback)
         self._tiled = False
         self._level_hw = [(h >> i, w >> i) for i in range(num_levels)]
         if not needs_grad and hasattr(GA, "gaussian_parameters"):
@@ -124,12 +125,12 @@ class CorrBlock:
             mean_n, cov, det = GA.gaussian_parameters(self.t)
             tiled = bool(CorrBlock.TILED_PYRAMID) and radius == 3
             try:
-                self.corr_pyramid = ops.volume_pyramid(mean_n.float().contiguous(), cov, volume.contiguous(), num_levels,
-                                                       GA.RADIUS, inplace=True, tiled=tiled)
+                self._adopt_store(ops.volume_pyramid(mean_n.float().contiguous(), cov, volume.contiguous(), num_levels,
+                                                     GA.RADIUS, inplace=True, tiled=tiled))
                 self._tiled = tiled
             except _lib.UnsupportedShape:
                 self.corr_pyramid = None
-        if self.corr_pyramid is None:
+        if self._store is None and self._pyr is None:
             volume, mean_n, det = GA(self.t, volume)
             # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
             self.corr_pyramid = []
@@ -140,6 +141,58 @@ class CorrBlock:
         self.mean_n = mean_n.view(b, n, h, w, 2)
         self.theta = 2 * det.view(b, n, h, w)
 
+    # ---- pyramid storage ----
+    # Inference blocks keep their pyramid in SLOT-INDIRECTED level buffers: `_store[l]` holds `capacity` edge slots,
+    # `_slot_list[e]` is the slot of logical edge e, the lookup kernel follows that indirection
+    # (lgu_defcorr_pyramid_slots_fwd_f32).  `cat` then copies only the NEW edges into free slots and `__getitem__`
+    # only edits the index list, where the reference (corr.py:111-121) re-materialises the whole multi-GB pyramid
+    # with torch.cat / boolean indexing on every keyframe.  `corr_pyramid` remains readable in edge order (a gathered
+    # copy) and assignable (which leaves the slot form).
+    def _adopt_store(self, levels):
+        self._store = list(levels)
+        self._pyr = None
+        n = levels[0].shape[0]
+        self._slot_list = list(range(n))
+        self._free = []
+        self._slots_dev = None
+        self._plan_key = None
+
+    def _slots(self):
+        if self._slots_dev is None or self._slots_dev.shape[0] != len(self._slot_list):
+            self._slots_dev = torch.tensor(self._slot_list, dtype=torch.int32, device=self._store[0].device)
+        return self._slots_dev
+
+    def _edge_order_levels(self):
+        if self._store is None:
+            return self._pyr
+        if self._slot_list == list(range(self._store[0].shape[0])):
+            return self._store
+        idx = self._slots().long()
+        return [st[idx] for st in self._store]
+
+    @property
+    def corr_pyramid(self):
+        return self._edge_order_levels()
+
+    @corr_pyramid.setter
+    def corr_pyramid(self, levels):
+        self._pyr = levels
+        self._store = None
+        self._plan_key = None
+
+    def _reserve(self, extra):
+        """Make room for `extra` more edges: grow every level buffer (amortised doubling)."""
+        cap = self._store[0].shape[0]
+        if len(self._free) >= extra:
+            return
+        newcap = max(2 * cap, cap + extra - len(self._free))
+        for l, st in enumerate(self._store):
+            grown = torch.empty((newcap,) + tuple(st.shape[1:]), dtype=st.dtype, device=st.device)
+            grown[:cap] = st
+            self._store[l] = grown
+        self._free += list(range(cap, newcap))
+        self._plan_key = None
+
     # ---- lookup ----
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
@@ -148,8 +201,8 @@ class CorrBlock:
         coords_xy = coords.reshape(E, ht, wd, 2)   # as handed over: x, y interleaved (the fused kernel reads this form)
         coords = None                               # (E,2,ht,wd) planes, made only where an operator needs them
 
-        needs_grad = torch.is_grad_enabled() and (
-            any(v.requires_grad for v in self.corr_pyramid) or any(o.requires_grad for o in self.offset))
+        needs_grad = torch.is_grad_enabled() and self._store is None and (
+            any(v.requires_grad for v in self._pyr) or any(o.requires_grad for o in self.offset))
         if needs_grad:
             coords = coords_xy.permute(0, 3, 1, 2).contiguous()
             # training: reference-shaped composition through the autograd Functions.
@@ -172,15 +225,19 @@ class CorrBlock:
                 o = o.float().contiguous()
                 self.offset[i] = o  # keep the buffer the kernel zeroes the centre of
             offs.append(o.view(E, ht, wd, rd, rd, 2))
-        pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
+        if self._store is not None:
+            pyr, slots = self._store, self._slots()
+        else:
+            pyr, slots = [v if v.is_contiguous() else v.contiguous() for v in self._pyr], None
         # inference: probe + mask + all levels + concatenation in ONE launch; offset[1] is
         # scaled in place by the kernel (the same persistent state as above).  The prepared
         # launch is rebuilt only when the pyramid / offset buffers change (cat, __getitem__).
-        key = tuple(t.data_ptr() for t in pyr) + tuple(o.data_ptr() if o is not None else 0 for o in offs)
+        key = tuple(t.data_ptr() for t in pyr) + tuple(o.data_ptr() if o is not None else 0 for o in offs) + \
+            ((slots.data_ptr(), slots.shape[0]) if slots is not None else ())
         try:
             if getattr(self, "_plan_key", None) != key:
                 self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True, tiled=self._tiled,
-                                                    level_hw=self._level_hw, coords_last=True)
+                                                    level_hw=self._level_hw, coords_last=True, slots=slots)
                 self._plan_key = key
             out = self._plan(coords_xy if coords_xy.is_contiguous() else coords_xy.contiguous())
         except _lib.UnsupportedShape:
@@ -188,7 +245,7 @@ class CorrBlock:
             self._plan_key = None
             self._to_reference_layout()
             coords = coords_xy.permute(0, 3, 1, 2).contiguous()
-            pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
+            pyr = [v if v.is_contiguous() else v.contiguous() for v in self._pyr]
             probe, = ops.corr_index_forward(pyr[1], (coords / 2).contiguous(), 1)
             self.offset[1] = (self.offset[1] * _uncertainty_mask(probe)).contiguous()
             offs[1] = self.offset[1].view(E, ht, wd, rd, rd, 2)
@@ -196,26 +253,50 @@ class CorrBlock:
         return out.view(batch, num, -1, ht, wd), self.mean_n, self.theta
 
     def _to_reference_layout(self):
-        """Row-major slices again (only needed to mix with a block built without the fused builder)."""
+        """Plain row-major level tensors in edge order (only needed to mix with a block built without the fused
+        builder, or for shapes the fused lookup does not serve)."""
+        levels = self._edge_order_levels()
         if self._tiled:
-            self.corr_pyramid = [ops.volume_retile(v.contiguous(), to_tiled=False, hw=self._level_hw[i])
-                                 for i, v in enumerate(self.corr_pyramid)]
+            levels = [ops.volume_retile(v.contiguous(), to_tiled=False, hw=self._level_hw[i]) for i, v in enumerate(levels)]
             self._tiled = False
-            self._plan_key = None
+        self.corr_pyramid = levels
 
     def cat(self, other):
-        if self._tiled != other._tiled:
-            self._to_reference_layout()
-            other._to_reference_layout()
+        if self._store is not None and other._store is not None and self._tiled == other._tiled:
+            # append: only the new edges move (into free slots of this block's buffers)
+            src = other._edge_order_levels()
+            n_new = src[0].shape[0]
+            self._reserve(n_new)
+            take, self._free = self._free[:n_new], self._free[n_new:]
+            if n_new:
+                idx = torch.tensor(take, dtype=torch.long, device=src[0].device)
+                for l in range(self.num_levels):
+                    self._store[l][idx] = src[l]
+            self._slot_list = self._slot_list + take
+            self._slots_dev = None
+        else:
+            if self._tiled != other._tiled or self._store is not None or other._store is not None:
+                self._to_reference_layout()
+                other._to_reference_layout()
+            self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self._pyr, other._pyr)]
         for i in range(self.num_levels):
-            self.corr_pyramid[i] = torch.cat([self.corr_pyramid[i], other.corr_pyramid[i]], 0)
             self.offset[i] = torch.cat([self.offset[i], other.offset[i]], 0)
             self._zero_level[i] = self._zero_level[i] and other._zero_level[i]
         return self
 
     def __getitem__(self, index):
+        if self._store is not None:
+            # drop / reorder edges: edit the slot list, return the dropped slots to the free list; no volume moves
+            n = len(self._slot_list)
+            keep = torch.arange(n, device=self._store[0].device)[index].tolist()
+            new_list = [self._slot_list[i] for i in keep]
+            kept = set(new_list)
+            self._free = self._free + [sl for sl in self._slot_list if sl not in kept]
+            self._slot_list = new_list
+            self._slots_dev = None
+        else:
+            self.corr_pyramid = [v[index] for v in self._pyr]
         for i in range(self.num_levels):
-            self.corr_pyramid[i] = self.corr_pyramid[i][index]
             self.offset[i] = self.offset[i][index]
         return self
 

@@ -54,6 +54,9 @@ struct PyrParams {
   // slice geometry: floats per (edge,pixel) slice and, for the tiled layout, 4x8 tiles per tile row
   int ssz[FASTL];
   int tpr[FASTL];
+  // optional storage indirection: edge e's volume slices live at slot edge_slot[e] of the level buffers (the state
+  // container appends / drops edges without moving the pyramid); null = slot e.  Offsets, coords, out stay by e.
+  const int* edge_slot;
 };
 
 // Position of target element (y, x) inside a slice.  Reference layout: row-major H2 x W2.
@@ -444,6 +447,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
 
   const size_t HW1 = (size_t)p.H1 * p.W1;
   const size_t row_pix = ((size_t)e * p.H1 + y) * p.W1;
+  const size_t vrow_pix = p.edge_slot ? ((size_t)p.edge_slot[e] * p.H1 + y) * p.W1 : row_pix;  // where the volume slices live
 
   // ---- phase 0: coords + offsets ----
   float x0[GP], y0[GP];
@@ -506,7 +510,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       const int H2 = p.H2[1], W2 = p.W2[1];
       const int X = (int)floorf(cs[k][1].x) - 1 + (lane & 3), Y = (int)floorf(cs[k][1].y) - 1 + ((lane >> 2) & 3);
       if (lane < 16 && in_bounds(Y, X, H2, W2))
-        platv[k] = p.vol[1][(row_pix + px) * (size_t)p.ssz[1] + slice_pos<TILED>(Y, X, W2, p.tpr[1])];
+        platv[k] = p.vol[1][(vrow_pix + px) * (size_t)p.ssz[1] + slice_pos<TILED>(Y, X, W2, p.tpr[1])];
     }
   }
 
@@ -526,7 +530,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;
     gflag[k][l] = (valid ? 1 : 0) | (xin ? 2 : 0) | (yin ? 4 : 0);
     const int dxo = xin ? step_x<TILED>(xc) : 0, dyo = yin ? step_y<TILED>(yc, W2, p.tpr[l]) : 0;
-    const float* s = p.vol[l] + (row_pix + (pv ? px : 0)) * (size_t)p.ssz[l] + slice_pos<TILED>(yc, xc, W2, p.tpr[l]);
+    const float* s = p.vol[l] + (vrow_pix + (pv ? px : 0)) * (size_t)p.ssz[l] + slice_pos<TILED>(yc, xc, W2, p.tpr[l]);
     q[k][l][0] = s[0];
     q[k][l][1] = s[dxo];
     q[k][l][2] = s[dyo];
@@ -549,7 +553,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
         if (PIXOP == 1) {
           const int X = (int)floorf(cs[k][l].x) - R + lx, Y = (int)floorf(cs[k][l].y) - R + ly;
           if (pv && lat_on && in_bounds(Y, X, H2, W2))
-            latv[k][l] = p.vol[l][(row_pix + px) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
+            latv[k][l] = p.vol[l][(vrow_pix + px) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
         } else if (k == 0) {
           const int pxl = xbase + w * GP + lpix;
           float cxl = cs[0][l].x, cyl = cs[0][l].y;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
             if (lpix == kk) { cxl = cs[kk][l].x; cyl = cs[kk][l].y; }
           const int X = (int)floorf(cxl) - R + lx, Y = (int)floorf(cyl) - R + ly;
           if (pxl < p.W1 && lpix < GP && lat_on && in_bounds(Y, X, H2, W2))
-            latv[k][l] = p.vol[l][(row_pix + pxl) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
+            latv[k][l] = p.vol[l][(vrow_pix + pxl) * (size_t)p.ssz[l] + slice_pos<TILED>(Y, X, W2, p.tpr[l])];
         }
       } else if (!(PROBE && l == 1)) {
         issue_level(k, l);
@@ -732,7 +736,7 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 // Host dispatcher shared by the three forward entry points.
 static int pyramid_forward(const float* const* volumes, const float* coords, float* const* offsets, float* out,
                            int L, int E, int H1, int W1, const int* H2, const int* W2, int radius, int flags,
-                           void* stream) {
+                           void* stream, const int* edge_slot = nullptr) {
   if (!volumes || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
   if (L < 1 || L > LGU_MAX_LEVELS || E < 0 || H1 < 1 || W1 < 1 || radius < 0 || radius > LGU_MAX_RADIUS)
     return LGU_E_BADARG;
@@ -780,8 +784,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       fast = fast && (tiled || W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
     // the tiled layout is served by the production gather kernel at radius 3 only (what CorrBlock builds)
     if (tiled && !(fast && radius == 3 && (variant == 0 || variant == 4 || variant == 5))) return LGU_E_UNSUPPORTED;
-    // interleaved coords are read by the register-gather kernels only
-    if (coords_last && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
+    // interleaved coords and slot-indirected volumes are served by the register-gather kernels only
+    if ((coords_last || edge_slot) && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {
@@ -793,7 +797,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
         p.tpr[l] = (p.W2[l] + 7) >> 3;
         p.ssz[l] = tiled ? ((p.H2[l] + 3) >> 2) * p.tpr[l] * 32 : p.H2[l] * p.W2[l];
       }
-      p.coords = coords; p.out = out;
+      p.coords = coords; p.out = out; p.edge_slot = edge_slot;
       p.L = nl; p.E = E; p.H1 = H1; p.W1 = W1;
       p.tiles_per_row = (W1 + TP - 1) / TP;
       p.Ctot = Ctot; p.cbase = l0 * nt; p.lbase = l0; p.flags = flags;
@@ -839,6 +843,12 @@ int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords
                                 int L, int E, int H1, int W1, const int* H2, const int* W2, int radius, int flags,
                                 void* stream) {
   return lgu::pyramid_forward(volumes, coords, offsets, out, L, E, H1, W1, H2, W2, radius, flags, stream);
+}
+
+int lgu_defcorr_pyramid_slots_fwd_f32(const float* const* volumes, const int* edge_slot, const float* coords,
+                                      float* const* offsets, float* out, int L, int E, int H1, int W1, const int* H2,
+                                      const int* W2, int radius, int flags, void* stream) {
+  return lgu::pyramid_forward(volumes, coords, offsets, out, L, E, H1, W1, H2, W2, radius, flags, stream, edge_slot);
 }
 
 int lgu_defcorr_fwd_f32(const float* volume, const float* coords, float* offset, float* corr, int E, int H1, int W1,

@@ -410,8 +410,10 @@ class DefcorrPyramidPlan:
     every update) and by bench.py so the step is not bound by Python argument handling.
     """
 
-    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False):
-        """coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1)."""
+    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False, slots=None):
+        """coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1).
+        slots: int32 device tensor (E,): edge e's volume slices live at volumes[l][slots[e]] (the level buffers may
+        hold more slots than E); offsets / coords / out stay indexed by e."""
         L = len(volumes)
         if len(offsets) != L:
             raise RuntimeError("DefcorrPyramidPlan: need one offset entry (tensor or None) per level")
@@ -421,11 +423,16 @@ class DefcorrPyramidPlan:
             if offsets[l] is not None:
                 named += [offsets[l], "offset[%d]" % l]
         _check(*named)
-        self._keep = (list(volumes), list(offsets))  # keep the buffers alive
+        if slots is not None:
+            _check_dtype(slots, "slots", torch.int32)
+        self._keep = (list(volumes), list(offsets), slots)  # keep the buffers alive
         self.L, self.radius = L, radius
         self.flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
         self.coords_last = coords_last
         self.E, self.H1, self.W1 = volumes[0].shape[:3]
+        if slots is not None:
+            self.E = slots.shape[0]
+        self._slots = slots.data_ptr() if slots is not None and slots.numel() else None
         self.device = volumes[0].device
         self.channels = L * (2 * radius + 1) ** 2
         self._vp = (_vp * L)(*[v.data_ptr() for v in volumes])
@@ -434,6 +441,7 @@ class DefcorrPyramidPlan:
         self._h2 = (ctypes.c_int * L)(*hs)
         self._w2 = (ctypes.c_int * L)(*ws)
         self._fn = _lib.load().lgu_defcorr_pyramid_fwd_f32
+        self._fn_slots = _lib.load().lgu_defcorr_pyramid_slots_fwd_f32
 
     def __call__(self, coords, out=None):
         want = (self.E, self.H1, self.W1, 2) if self.coords_last else (self.E, 2, self.H1, self.W1)
@@ -444,8 +452,12 @@ class DefcorrPyramidPlan:
             out = torch.empty((self.E, self.channels, self.H1, self.W1), dtype=torch.float32, device=self.device)
         if self.E == 0:
             return out
-        rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
-                      self._h2, self._w2, self.radius, self.flags,
-                      torch.cuda.current_stream(self.device).cuda_stream)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if self._slots is not None:
+            rc = self._fn_slots(self._vp, self._slots, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1,
+                                self.W1, self._h2, self._w2, self.radius, self.flags, st)
+        else:
+            rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
+                          self._h2, self._w2, self.radius, self.flags, st)
         _lib.check(rc, "defcorr_pyramid_forward")
         return out

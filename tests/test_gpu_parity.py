@@ -876,3 +876,48 @@ def test_lowmem_pyramid_reads_frame_buffers_in_place(lgu, half):
     assert torch.equal(probe, alt)
     with pytest.raises(RuntimeError, match="both ii and jj"):
         lgu.ops.LowmemPyramidPlan(frames[0], frames, oa, 3, ii=ii)
+
+
+def test_corrblock_slot_store_cat_and_getitem_move_no_volume(lgu):
+    """The inference CorrBlock keeps its pyramid in slot-indirected buffers: `cat` copies only the new edges,
+    `__getitem__` (bool mask, as factor_graph.rm_factors uses, or an index tensor) only edits the slot list, freed
+    slots are reused; the edge-ordered view of the pyramid and the lookup equal those of a block built from exactly
+    those edges.  (Lookups are compared on fresh blocks only: a lookup leaves persistent state in offset[1].)"""
+    torch.manual_seed(9)
+    E, h, w = 6, 24, 32
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    GA = lgu.GaussianMask(h, w).cuda()
+    f1 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda").float(), torch.arange(w, device="cuda").float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device="cuda")
+
+    def block(sel):
+        sel = torch.as_tensor(sel, device="cuda")
+        return lgu.CorrBlock(ofsMap, ofsRes, GA, f1[:, sel], f2[:, sel])
+
+    def same_pyramid(blk, sel):   # two constructions differ by conv / matmul rounding only
+        return all(float((a - b).abs().max()) <= 2e-5 for a, b in zip(blk.corr_pyramid, block(sel).corr_pyramid))
+
+    with torch.no_grad():
+        blk = block([0, 1, 2])
+        assert blk._store is not None and blk._tiled
+        blk.cat(block([3, 4]))
+        assert len(blk._slot_list) == 5 and blk._store[0].shape[0] >= 5          # grown once (doubling)
+        grown_ptr = blk._store[0].data_ptr()
+        assert same_pyramid(blk, [0, 1, 2, 3, 4])
+        blk[torch.tensor([False, True, True, False, True], device="cuda")]       # rm_factors-style boolean mask
+        assert blk._slot_list == [1, 2, 4] and sorted(blk._free)[:2] == [0, 3] and blk._store[0].data_ptr() == grown_ptr
+        assert same_pyramid(blk, [1, 2, 4]) and blk.offset[0].shape[0] == 3
+        blk.cat(block([5]))                                                      # reuses a freed slot, no growth
+        assert blk._store[0].data_ptr() == grown_ptr and len(blk._slot_list) == 4 and blk._slot_list[-1] in (0, 3, 5)
+        assert same_pyramid(blk, [1, 2, 4, 5])
+        blk[torch.tensor([3, 0], device="cuda")]                                  # reorder with an index tensor
+        assert same_pyramid(blk, [5, 1])
+        got = blk(coords[:, [5, 1]])[0]                                           # first lookup of this block
+        assert float((got - block([5, 1])(coords[:, [5, 1]])[0]).abs().max()) <= 2e-5
+        # corr_pyramid stays readable in edge order (gathered copy), and assigning it leaves the slot form
+        lv = [v.clone() for v in blk.corr_pyramid]
+        blk.corr_pyramid = lv
+        assert blk._store is None and blk.corr_pyramid[0].shape[0] == 2
