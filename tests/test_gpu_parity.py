@@ -921,3 +921,23 @@ def test_corrblock_slot_store_cat_and_getitem_move_no_volume(lgu):
         lv = [v.clone() for v in blk.corr_pyramid]
         blk.corr_pyramid = lv
         assert blk._store is None and blk.corr_pyramid[0].shape[0] == 2
+
+
+def test_lowmem_pyramid_backend_scale_indexed(lgu):
+    """BASELINE config 5 per-GPU scale: 250 edges over 40 frames of 60x80x128 half feature maps, all levels in one
+    launch reading the frame buffers in place.  The last edges (largest work-item ids / output addresses) equal a
+    small launch over just those edges; everything is finite."""
+    torch.manual_seed(17)
+    F_, H, W, C, L, E = 40, 60, 80, 128, 4, 250
+    frames = [(torch.randn(F_, H >> l, W >> l, C, device="cuda") * 0.125).half() for l in range(L)]
+    ii = torch.randint(0, F_, (E,), device="cuda")
+    jj = torch.randint(0, F_, (E,), device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(E, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = (4 * torch.tanh(torch.randn(1, H, W, 7, 7, 2, device="cuda"))).contiguous()   # offset[b*n] -> edge 0's offsets
+    out = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], frames, coords, [o0, None, None, None], 3, ii=ii, jj=jj)
+    assert out.shape == (E, 1, 196, H, W) and torch.isfinite(out).all()
+    tail = slice(E - 3, E)
+    small = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], frames, coords[tail].contiguous(), [o0.clone(), None, None, None], 3,
+                                                 ii=ii[tail].contiguous(), jj=jj[tail].contiguous())
+    assert torch.equal(out[tail], small)
