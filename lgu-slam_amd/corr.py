@@ -288,7 +288,7 @@ class CorrBlock:
         if self._store is not None:
             # drop / reorder edges: edit the slot list, return the dropped slots to the free list; no volume moves
             n = len(self._slot_list)
-            keep = torch.arange(n, device=self._store[0].device)[index].tolist()
+            keep = torch.arange(n, device=self._store[0].device)[index].reshape(-1).tolist()
             new_list = [self._slot_list[i] for i in keep]
             kept = set(new_list)
             self._free = self._free + [sl for sl in self._slot_list if sl not in kept]

@@ -230,6 +230,7 @@ LOWMEM_CASES = [
     (1, 1, 24, 32, 24, 32, 64, 3, 3.0, 1.0, 14.0),   # boxes > 256 positions: per-pixel fallback
     (1, 1, 60, 80, 60, 80, 32, 3, 40.0, 1.0, 4.0),   # scattered coords: tile window > LDS budget, per-tap fallback
     (1, 1, 12, 16, 12, 16, 40, 2, 3.0, 1.0, 3.0),    # radius 2, C = 40 (C % 8 == 0, C % 32 != 0 is rejected by the ABI)
+    (3, 2, 10, 13, 10, 13, 64, 3, 3.0, 1.0, 4.0),    # B = 3, S = 2: offset[b*s] takes rows 0, 1, 2 (reference indexing), ragged block grid
 ]
 
 
@@ -358,6 +359,7 @@ MIXED_CASES = [(2, 1, 60, 80, 60, 80, 128, 3, 3.0, 1.0, 4.0), (2, 1, 60, 80, 30,
                # ragged sizes (H1, W1 not multiples of the 4x4 block / 8x8 tile), 9 edges (XCD dealing with a tail),
                # C = 256, radius 2, border stress
                (9, 1, 10, 13, 7, 9, 128, 3, 6.0, 0.5, 4.0), (2, 1, 12, 16, 12, 16, 256, 2, 3.0, 1.0, 3.0),
+               (3, 2, 10, 13, 10, 13, 64, 3, 3.0, 1.0, 4.0),
                (1, 1, 17, 23, 17, 23, 128, 3, 20.0, 1.0, 4.0)]
 
 

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""End-to-end cost of the glue classes per call (wall time incl. Python, one MI355X): CorrBlock lookup (20 edges,
+48x64), CorrBlock construction, cat / boolean-mask pruning, AltCorrBlock lookup (16 edges over 8 frames, 60x80)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lgu_slam_amd as lgu  # noqa: E402
+
+dev = "cuda"
+torch.manual_seed(0)
+
+
+def wall(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+with torch.no_grad():
+    E, h, w = 20, 48, 64
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+    GA = lgu.GaussianMask(h, w).to(dev)
+    f1 = torch.randn(1, E, 128, h, w, device=dev) * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device=dev) * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev).float(), torch.arange(w, device=dev).float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device=dev)
+    blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+    res = {"CorrBlock.__call__ 20 edges 48x64 (ms, wall incl. Python)": wall(lambda: blk(coords)),
+           "CorrBlock.__init__ 20 edges (matmul + offsets convs + fused pyramid)": wall(lambda: lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2), iters=10, warm=2)}
+    new = lgu.CorrBlock(ofsMap, ofsRes, GA, f1[:, :4], f2[:, :4])
+    mask = torch.ones(24, dtype=torch.bool, device=dev)
+    mask[:4] = False
+
+    def grow_and_prune():
+        blk.cat(new)      # 4 new edges appended into free slots
+        blk[mask]         # the 4 oldest dropped: slot list edit only
+
+    res["CorrBlock.cat(4 edges) + [bool mask] on a 20-edge block (slot store)"] = wall(grow_and_prune, iters=20, warm=3)
+    lgu.CorrBlock.TILED_PYRAMID = False
+    ref_like = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+    ref_like.corr_pyramid = [v.clone() for v in ref_like.corr_pyramid]   # plain tensors: torch.cat / indexing as the reference does
+    new2 = lgu.CorrBlock(ofsMap, ofsRes, GA, f1[:, :4], f2[:, :4])
+    new2.corr_pyramid = [v.clone() for v in new2.corr_pyramid]
+
+    def grow_and_prune_ref():
+        ref_like.cat(new2)
+        ref_like[mask]
+
+    res["the same with plain tensors (torch.cat + boolean indexing, as the reference)"] = wall(grow_and_prune_ref, iters=20, warm=3)
+    lgu.CorrBlock.TILED_PYRAMID = True
+
+    N, H, W = 8, 60, 80
+    fm = (torch.randn(1, N, 128, H, W, device=dev) * 0.5).half()
+    ii = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7], device=dev)
+    jj = torch.tensor([1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 0, 0, 1], device=dev)
+    ysb, xsb = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing="ij")
+    cb = torch.stack([xsb, ysb], -1)[None, None] + 2 * torch.randn(1, 16, H, W, 2, device=dev)
+    alt = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
+    res["AltCorrBlock.__call__ 16 edges 60x80 half (offset convs + probe + fused launch)"] = wall(lambda: alt(cb, ii, jj), iters=20, warm=3)
+print(json.dumps(res, indent=1))
