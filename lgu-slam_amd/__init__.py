@@ -13,7 +13,7 @@ from . import _build, _lib, ops, sharded  # noqa: F401
 from .corr import AltCorrBlock, CorrBlock, CorrSampler, DefCorrSampler, per_Corr_Normalization  # noqa: F401
 from .gaussian_mask import GaussianMask, GaussianMaskCuda  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 DROPIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
 
