@@ -943,3 +943,71 @@ def test_lowmem_pyramid_backend_scale_indexed(lgu):
     small = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], frames, coords[tail].contiguous(), [o0.clone(), None, None, None], 3,
                                                  ii=ii[tail].contiguous(), jj=jj[tail].contiguous())
     assert torch.equal(out[tail], small)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomized_differential_pyramid(lgu, seed):
+    """Seeded random shapes (ragged sizes, 1-4 levels, border-heavy coords, huge offsets): the production kernels
+    over both pyramid layouts against the independent one-thread-per-output kernel (variant 2)."""
+    rng = np.random.default_rng(1000 + seed)
+    E = int(rng.integers(1, 4))
+    H1 = int(rng.integers(5, 40))
+    W1 = int(rng.integers(5, 70))
+    L = int(rng.integers(1, 5))
+    while (H1 >> (L - 1)) < 1 or (W1 >> (L - 1)) < 1:
+        L -= 1
+    sigma = float(rng.choice([1.0, 3.0, 12.0, 40.0]))
+    osc = float(rng.choice([2.0, 4.0, 9.0]))
+    dense = bool(rng.integers(0, 2))
+    case = inputs.pyramid_case(2000 + seed, E, H1, W1, L, 3, sigma, osc, dense)
+    vols = [dev(v) for v in case["volumes"]]
+    hw = [tuple(v.shape[3:]) for v in vols]
+    coords = dev(case["coords"])
+
+    def fresh():
+        return [dev(o) if o is not None else None for o in case["offsets"]]
+
+    set_variant(2)
+    o_ref = fresh()
+    want = lgu.ops.defcorr_pyramid_forward(vols, coords, o_ref, 3)
+    set_variant(0)
+    o_t = fresh()
+    got_t = lgu.ops.defcorr_pyramid_forward([lgu.ops.volume_retile(v) for v in vols], coords, o_t, 3, tiled=True, level_hw=hw)
+    assert torch.equal(got_t, want), (E, H1, W1, L, sigma, osc, dense)
+    assert all(a is None or torch.equal(a, b) for a, b in zip(o_t, o_ref))
+    o_r = fresh()
+    got_r = lgu.ops.defcorr_pyramid_forward(vols, coords, o_r, 3)
+    assert torch.equal(got_r, want)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomized_differential_lowmem(lgu, seed):
+    """Seeded random shapes for the low-memory path: matrix-core kernels (float and half maps, per level and fused)
+    against the independent wave-per-pixel kernel (variant 1)."""
+    rng = np.random.default_rng(3000 + seed)
+    B = int(rng.integers(1, 11))
+    H1 = int(rng.integers(3, 30))
+    W1 = int(rng.integers(3, 40))
+    C = int(rng.choice([32, 64, 128]))
+    radius = int(rng.choice([1, 2, 3]))
+    L = int(rng.integers(1, 4))
+    sigma = float(rng.choice([1.0, 3.0, 10.0, 30.0]))
+    osc = float(rng.choice([2.0, 4.0, 8.0]))
+    rd = 2 * radius + 1
+    f1 = dev((rng.standard_normal((B, H1, W1, C)) * 0.125).astype(np.float32)).half().float()   # exactly representable in half
+    f2s = [dev((rng.standard_normal((B, max(H1 >> l, 1), max(W1 >> l, 1), C)) * 0.125).astype(np.float32)).half().float() for l in range(L)]
+    ys, xs = np.meshgrid(np.arange(H1, dtype=np.float32), np.arange(W1, dtype=np.float32), indexing="ij")
+    coords = dev((np.stack([xs, ys], -1)[None, None].repeat(B, 0) + rng.standard_normal((B, 1, H1, W1, 2)) * sigma).astype(np.float32))
+    off = [dev((osc * np.tanh(rng.standard_normal((B, H1, W1, rd, rd, 2)))).astype(np.float32)) for _ in range(L)]
+    os.environ["LGU_LOWMEM_VARIANT"] = "1"
+    try:
+        want = [lgu.ops.lowMem_defSample(f1, f2s[l], (coords / 2 ** l).contiguous(), off[l].clone(), radius)[0].view(B, 1, rd * rd, H1, W1)
+                for l in range(L)]
+    finally:
+        os.environ.pop("LGU_LOWMEM_VARIANT")
+    want = torch.cat(want, 2)
+    got_f = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o.clone() for o in off], radius)
+    got_h = lgu.ops.lowmem_pyramid_forward_mixed(f1.half(), [f.half() for f in f2s], coords, [o.clone() for o in off], radius)
+    tag = (B, H1, W1, C, radius, L, sigma, osc)
+    assert float((got_f - want).abs().max()) <= 1e-5, tag
+    assert float((got_h - want).abs().max()) <= 1e-5, tag
