@@ -184,3 +184,58 @@ def test_non_finite_and_wild_coordinates_match_reference(lgu, ref):
     b, = lgu.ops.lowMem_defSample(dev(fc["fmap1"]), dev(fc["fmap2"]), dev(cc), dev(fc["offset"]), 3)
     assert torch.equal(torch.isnan(a), torch.isnan(b))
     assert torch.allclose(a, b, rtol=0, atol=1e-5, equal_nan=True)
+
+
+def test_half_feature_maps_and_fused_levels_vs_reference_call_sequence(lgu, ref, refalt):
+    """What AltCorrBlock issues for half feature buffers — the level-1 probe and all levels in one launch on the
+    matrix cores — against the reference's own call sequence on the `.float()` copies (corr.py:192-213):
+    altcorr_forward + 4 x lowMem_defSample + cat, BASELINE config 4 shapes."""
+    torch.manual_seed(31)
+    B, H, W, C, L = 3, 60, 80, 128, 4
+    f1 = (torch.randn(B, H, W, C, device="cuda") * 0.125).half()
+    f2s = [(torch.randn(B, H >> l, W >> l, C, device="cuda") * 0.125).half() for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, device="cuda")).contiguous()
+    offs = [(4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device="cuda"))).contiguous() for _ in range(2)]
+    offs += [torch.zeros(B, H, W, 7, 7, 2, device="cuda") for _ in range(2)]
+    want = torch.cat([ref.lowMem_defSample(f1.float(), f2s[l].float(), (coords / 2 ** l).contiguous(), offs[l].clone(), 3)[0]
+                      .view(B, 1, 49, H, W) for l in range(L)], 2)
+    got = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [offs[0].clone(), offs[1].clone(), None, None], 3)
+    assert close(got, want)
+    pa, = refalt.altcorr_forward(f1.float(), f2s[1].float(), (coords / 2).contiguous(), 1)
+    pb = lgu.ops.lowmem_pyramid_forward_mixed(f1, [f2s[1]], coords, [None], 1, lbase=1)
+    assert close(pb, pa)
+    # float maps through the fp32 matrix-core kernel
+    gotf = lgu.ops.lowmem_pyramid_forward_mixed(f1.float(), [f.float() for f in f2s], coords, [offs[0].clone(), offs[1].clone(), None, None], 3)
+    assert close(gotf, want)
+
+
+def test_non_finite_coordinates_new_paths_match_reference(lgu, ref):
+    """NaN / inf / huge coordinates through the tiled pyramid layout, the interleaved-coords form and the half
+    matrix-core low-memory kernel: same NaN positions and values as the reference kernels, nothing faults."""
+    case = inputs.pyramid_case(557, 1, 16, 32, 2, 3, 3.0, 4.0, True)
+    c = case["coords"].copy()
+    c[0, 0, 0, :8] = np.nan
+    c[0, 1, 1, :8] = np.inf
+    c[0, 0, 2, :8] = -np.inf
+    c[0, :, 3, :8] = 3.0e9
+    c[0, :, 4, :8] = -3.0e9
+    vols = [dev(v) for v in case["volumes"]]
+    hw = [tuple(v.shape[3:]) for v in vols]
+    cd = dev(c)
+    want = torch.cat([ref.defCorr_index_forward(vols[l], (cd / 2 ** l).contiguous(), dev(case["offsets"][l]), 3)[0].view(1, 49, 16, 32)
+                      for l in range(2)], 1)
+    got = lgu.ops.defcorr_pyramid_forward([lgu.ops.volume_retile(v) for v in vols], cd.permute(0, 2, 3, 1).contiguous(),
+                                          [dev(o) for o in case["offsets"]], 3, tiled=True, level_hw=hw, coords_last=True)
+    assert torch.equal(torch.isnan(want), torch.isnan(got))
+    assert torch.allclose(want, got, rtol=0, atol=1e-6, equal_nan=True)
+    fc = inputs.fmap_case(558, 2, 1, 8, 16, 8, 16, 64, 3, 3.0, 1.0)
+    cc = fc["coords"].copy()
+    cc[0, 0, 0, :4, 0] = np.nan
+    cc[0, 0, 1, :4, 1] = np.inf
+    cc[1, 0, 2, :4, :] = -2.5e9
+    f1h, f2h = dev(fc["fmap1"]).half(), dev(fc["fmap2"]).half()
+    a, = ref.lowMem_defSample(f1h.float(), f2h.float(), dev(cc), dev(fc["offset"]), 3)
+    b, = lgu.ops.lowMem_defSample_mixed(f1h, f2h, dev(cc), dev(fc["offset"]), 3)
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    assert torch.allclose(a, b, rtol=0, atol=1e-5, equal_nan=True)
