@@ -213,6 +213,33 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
                                int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
                                int radius, const long long* ii, const long long* jj, void* stream);
 
+/* ---- dense bundle adjustment: device kernels (first version) ---------------------------
+ * The data-parallel kernels of droid_backends.ba (reference src/droid.cpp:88-107 -> src/droid_kernels.cu:1314-1434).
+ * The reference's host driver copies every block to the CPU and solves with Eigen; here lgu-slam_amd/ba.py assembles
+ * and solves the reduced camera system on the device and calls these for its operands.  All index arrays are int64
+ * device arrays (the dtype the reference's tensors have).  PARITY UNPINNED: see oracle/ba_oracle.py.
+ *
+ * lgu_ba_build_f32        projective_transform_kernel (:176-425): per edge e = (ii[e] -> jj[e]): reprojection residual of
+ *   targets (E,2,ht,wd) with weights (E,2,ht,wd), pose / depth Jacobians; Hs (4,E,6,6) = Hii,Hij,Hji,Hjj, vs (2,E,6),
+ *   Eii, Eij (E,6,ht*wd), Cii, wi (E,ht*wd), all fully written.  poses (N,7) = t, q(xyzw); disps (N,ht,wd); intrinsics (4).
+ * lgu_ba_accum_f32        accum_kernel (:854-874): out[j] = sum of inp rows idxs[ptrs[j] .. ptrs[j+1]), rows of D floats.
+ * lgu_ba_eet_f32          EEt6x6_kernel (:1001-1056): S[b] = (E[idx[b][0]] * Q[idx[b][2]]) E[idx[b][1]]^T, idx (nblocks,3).
+ * lgu_ba_ev_f32           Ev6x1_kernel (:1059-1093): v[n] = E[n] (Q[kk[n]] * w[kk[n]]), fully written.
+ * lgu_ba_evt_f32          EvT6x1_kernel (:1095-1115): dw[n] = E[n]^T x[idx[n]], zero rows where idx[n] <= 0 or >= P
+ *                         (the reference's condition, kept).
+ * lgu_ba_pose_retr_f32    pose_retr_kernel (:898-931): poses[k] <- exp(dx[k-t0]) * poses[k], k in [t0, t1).
+ * lgu_ba_disp_retr_f32    disp_retr_kernel (:933-946): disps[inds[b]] += dz[b]. */
+int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
+                     const float* intrinsics, const long long* ii, const long long* jj,
+                     float* Hs, float* vs, float* Eii, float* Eij, float* Cii, float* wi,
+                     int E, int ht, int wd, void* stream);
+int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* idxs, float* out, int nout, int D, void* stream);
+int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* S, int nblocks, int D, void* stream);
+int lgu_ba_ev_f32(const float* E, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream);
+int lgu_ba_evt_f32(const float* E, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream);
+int lgu_ba_pose_retr_f32(float* poses, const float* dx, int t0, int t1, void* stream);
+int lgu_ba_disp_retr_f32(float* disps, const float* dz, const long long* inds, int n, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

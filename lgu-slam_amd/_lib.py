@@ -36,6 +36,13 @@ SIGNATURES = {
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
     "lgu_lowmem_pyramid_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
+    "lgu_ba_build_f32": [_vp] * 13 + [_int] * 3 + [_vp],
+    "lgu_ba_accum_f32": [_vp] * 4 + [_int] * 2 + [_vp],
+    "lgu_ba_eet_f32": [_vp] * 4 + [_int] * 2 + [_vp],
+    "lgu_ba_ev_f32": [_vp] * 5 + [_int] * 2 + [_vp],
+    "lgu_ba_evt_f32": [_vp] * 4 + [_int] * 3 + [_vp],
+    "lgu_ba_pose_retr_f32": [_vp] * 2 + [_int] * 2 + [_vp],
+    "lgu_ba_disp_retr_f32": [_vp] * 3 + [_int] * 2 + [_vp],
     "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],
 }
 

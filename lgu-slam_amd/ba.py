@@ -1,0 +1,152 @@
+"""Dense bundle adjustment on the device: this build's counterpart of `droid_backends.ba`
+(reference src/droid.cpp:88-107 -> src/droid_kernels.cu:1314-1434 `ba_cuda`).  SURVEY §8 row f3, first version.
+
+Same signature, same in-place updates of `poses` and `disps`, same return value `[dx, dz]`.  What differs is the
+host side: the reference copies every 6x6 block to the CPU, assembles an Eigen sparse matrix in double and solves with
+SimplicialLLT once per iteration (host round trips inside the loop); here the reduced camera system is assembled
+(index_add on a dense (6P)^2 double matrix), damped and solved by Cholesky on the device — the data-parallel operands
+come from the HIP kernels of csrc/ba.hip.  The only host work is the graph bookkeeping (which E blocks meet in which
+depth frame), built once per call from ii / jj exactly as the reference's schur_block / accum_cuda do on the CPU.
+
+PARITY UNPINNED (the reference needs Eigen, absent in this image): checked against oracle/ba_oracle.py, which is itself
+pinned only by self-consistency tests (tests/test_ba.py).
+"""
+import torch
+
+from . import _lib
+from .ops import _check, _check_dtype, _ptr, _stream
+
+_ALPHA = 0.05  # droid_kernels.cu:1394
+
+
+def _segments(ix, jx):
+    """accum_cuda's bookkeeping (:948-982): for every j, the rows n with ix[n] == jx[j]."""
+    order = sorted(range(len(ix)), key=lambda n: ix[n])
+    ptrs, cols, i = [0], [], 0
+    for j in jx:
+        while i < len(order) and ix[order[i]] <= j:
+            if ix[order[i]] == j:
+                cols.append(order[i])
+            i += 1
+        ptrs.append(len(cols))
+    return ptrs, cols
+
+
+def _accum(lib, data, ix, jx, st):
+    """out[j] = sum of data[n] over ix[n] == jx[j] (accum_cuda :948-998); data (n, D) float32 on the device."""
+    dev = data.device
+    ptrs, cols = _segments(ix, jx)
+    out = torch.empty((len(jx), data.shape[1]), dtype=torch.float32, device=dev)
+    if len(jx) == 0:
+        return out
+    p = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+    c = torch.tensor(cols if cols else [0], dtype=torch.int64, device=dev)
+    _lib.check(lib.lgu_ba_accum_f32(_ptr(data), _ptr(p), _ptr(c), _ptr(out), len(jx), data.shape[1], st), "ba accum")
+    return out
+
+
+def _solve(A, b, lm, ep):
+    """SparseBlock::solve (:1206-1231): (A + diag(ep + lm * diag A)) x = b by Cholesky in double; zeros if not SPD."""
+    L = A.clone()
+    dg = torch.diagonal(L)
+    dg += ep + lm * dg
+    chol, info = torch.linalg.cholesky_ex(L)
+    if int(info) != 0:
+        return torch.zeros_like(b)
+    return torch.cholesky_solve(b[:, None], chol)[:, 0]
+
+
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
+    _check(poses, "poses", disps, "disps", intrinsics, "intrinsics", disps_sens, "disps_sens", targets, "targets",
+           weights, "weights")
+    _check_dtype(ii, "ii", torch.int64)
+    _check_dtype(jj, "jj", torch.int64)
+    lib = _lib.load()
+    dev = poses.device
+    E = ii.shape[0]
+    ht, wd = disps.shape[1:]
+    HW = ht * wd
+    P = t1 - t0
+    f32, f64 = torch.float32, torch.float64
+    with torch.cuda.device(dev):
+        st = _stream(poses)
+        ii_h, jj_h = ii.tolist(), jj.tolist()     # graph bookkeeping on the host, once per call
+        ts_h = list(range(t0, t1))
+        ii_exp_h, jj_exp_h = ts_h + ii_h, ts_h + jj_h
+        kx_h = sorted(set(ii_exp_h))
+        kpos = {f: n for n, f in enumerate(kx_h)}
+        kk_h = [kpos[f] for f in ii_exp_h]
+        kx = torch.tensor(kx_h, dtype=torch.int64, device=dev)
+        kk = torch.tensor(kk_h, dtype=torch.int64, device=dev)
+        # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
+        bi = torch.cat([ii, ii, jj, jj]) - t0
+        bj = torch.cat([ii, jj, ii, jj]) - t0
+        keep = (bi >= 0) & (bj >= 0)
+        flat = (bi * P + bj)[keep]
+        vi = torch.cat([ii, jj]) - t0
+        vkeep = vi >= 0
+        if not motion_only:
+            # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
+            graph = [[] for _ in range(P)]
+            index = [[] for _ in range(P)]
+            for n, (j, k) in enumerate(zip(jj_exp_h, kk_h)):
+                if t0 <= j < t1:
+                    graph[j - t0].append(k)
+                    index[j - t0].append(n)
+            trip, pi, pj = [], [], []
+            for i in range(P):
+                for j in range(P):
+                    for a, ka in zip(index[i], graph[i]):
+                        for c, kc in zip(index[j], graph[j]):
+                            if ka == kc:
+                                trip += [a, c, ka]
+                                pi.append(i)
+                                pj.append(j)
+            trip_t = torch.tensor(trip if trip else [0, 0, 0], dtype=torch.int64, device=dev).view(-1, 3)
+            sflat = torch.tensor([a * P + b for a, b in zip(pi, pj)], dtype=torch.int64, device=dev)
+            jpose = torch.tensor(jj_exp_h, dtype=torch.int64, device=dev) - t0
+            jkeep = jpose >= 0
+            m = (disps_sens[kx] > 0).to(f32).view(-1, HW)
+            eta_v = eta.reshape(-1, HW).to(f32)
+
+        Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
+        vs = torch.empty((2, E, 6), dtype=f32, device=dev)
+        Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
+        Eij = torch.empty((E, 6, HW), dtype=f32, device=dev)
+        Cii = torch.empty((E, HW), dtype=f32, device=dev)
+        wi = torch.empty((E, HW), dtype=f32, device=dev)
+        dx = torch.zeros((P, 6), dtype=f32, device=dev)
+        dz = None
+        for _ in range(iterations):
+            _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
+                                            _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), E, ht, wd, st),
+                       "ba build")
+            A = torch.zeros((P * P, 6, 6), dtype=f64, device=dev)
+            A.index_add_(0, flat, Hs.view(-1, 6, 6)[keep].to(f64))
+            b = torch.zeros((P, 6), dtype=f64, device=dev)
+            b.index_add_(0, vi[vkeep], vs.view(-1, 6)[vkeep].to(f64))
+            if not motion_only:
+                C = _accum(lib, Cii, ii_h, kx_h, st) + m * _ALPHA + (1 - m) * eta_v                       # :1396
+                w = _accum(lib, wi, ii_h, kx_h, st) - m * _ALPHA * (disps[kx] - disps_sens[kx]).view(-1, HW)   # :1397
+                Q = (1.0 / C).contiguous()
+                w = w.contiguous()
+                Ei = _accum(lib, Eii.view(E, 6 * HW), ii_h, ts_h, st).view(P, 6, HW)                     # :1400
+                Eall = torch.cat([Ei, Eij], 0).contiguous()                                             # :1401
+                nE = Eall.shape[0]
+                S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
+                if trip:
+                    _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
+                    A.index_add_(0, sflat, -S.to(f64))
+                sv = torch.empty((nE, 6), dtype=f32, device=dev)
+                _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
+                b.index_add_(0, jpose[jkeep], -sv[jkeep].to(f64))
+            Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P)
+            dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+            if not motion_only:
+                dw = torch.empty((nE, HW), dtype=f32, device=dev)
+                _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose.contiguous()), _ptr(dw), nE, HW, P, st), "ba EvT")
+                dz = (Q * (w - _accum(lib, dw, ii_exp_h, kx_h, st))).contiguous()                       # :1415
+            _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
+            if not motion_only:
+                _lib.check(lib.lgu_ba_disp_retr_f32(_ptr(disps), _ptr(dz), _ptr(kx), kx.shape[0], HW, st), "ba disp retraction")
+    return [dx, dz]

@@ -1,0 +1,383 @@
+// ba.hip — data-parallel kernels of the dense bundle adjustment (first version).
+//
+// Replaces, in reference src/droid_kernels.cu: projective_transform_kernel (:176-425), accum_kernel (:854-874),
+// EEt6x6_kernel (:1001-1056), Ev6x1_kernel (:1059-1093), EvT6x1_kernel (:1095-1115), pose_retr_kernel (:898-931),
+// disp_retr_kernel (:933-946).  The reference's host side (ba_cuda :1314-1434) ships every Hessian block to the CPU
+// and solves with Eigen::SimplicialLLT; here the reduced camera system is assembled and solved on the device by the
+// host glue (lgu-slam_amd/ba.py), these kernels produce and consume its operands.
+//
+// PARITY UNPINNED: the reference BA cannot be built in this image (Eigen absent); the kernels are held to
+// oracle/ba_oracle.py, a line-by-line restatement checked by self-consistency tests (tests/test_ba.py).
+//
+// Mapping: one workgroup of 256 threads (4 waves) per edge / per output block, lanes over pixels with fully coalesced
+// reads of the per-pixel planes; per-thread partial sums are reduced with DPP inside the wave and through LDS
+// across the 4 waves (the reference's 256-entry shared-memory tree per scalar is 78 + 12 block reductions).
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+constexpr float BA_MIN_DEPTH = 0.25f;  // droid_kernels.cu:26
+constexpr int BA_THREADS = 256;
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void act_so3(const float* q, const float* X, float* Y) {  // :56-67
+  float uv[3], t[3];
+  cross3(q, X, uv);
+  uv[0] *= 2.0f; uv[1] *= 2.0f; uv[2] *= 2.0f;
+  cross3(q, uv, t);
+  Y[0] = X[0] + q[3] * uv[0] + t[0];
+  Y[1] = X[1] + q[3] * uv[1] + t[1];
+  Y[2] = X[2] + q[3] * uv[2] + t[2];
+}
+__device__ __forceinline__ void adj_se3(const float* t, const float* q, const float* X, float* Y) {  // :78-93
+  const float qinv[4] = {-q[0], -q[1], -q[2], q[3]};
+  act_so3(qinv, X, Y);
+  act_so3(qinv, X + 3, Y + 3);
+  const float u[3] = {t[2] * X[1] - t[1] * X[2], t[0] * X[2] - t[2] * X[0], t[1] * X[0] - t[0] * X[1]};
+  float v[3];
+  act_so3(qinv, u, v);
+  Y[3] += v[0]; Y[4] += v[1]; Y[5] += v[2];
+}
+__device__ __forceinline__ void rel_se3(const float* ti, const float* qi, const float* tj, const float* qj, float* tij,
+                                        float* qij) {  // :95-107
+  qij[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
+  qij[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
+  qij[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
+  qij[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
+  act_so3(qij, ti, tij);
+  tij[0] = tj[0] - tij[0]; tij[1] = tj[1] - tij[1]; tij[2] = tj[2] - tij[2];
+}
+
+// Sum of `v` over the workgroup's 256 threads, valid in thread 0 (and every lane of wave 0).
+__device__ __forceinline__ float block_sum(float v, float* red /* [4] */) {
+  v = wave_sum_f32(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // `red` may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- projective transform, residuals, Jacobians, per-edge Hessian blocks (:176-425) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
+    const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ poses,
+    const float* __restrict__ disps, const float* __restrict__ intrinsics, const long long* __restrict__ ii,
+    const long long* __restrict__ jj, float* __restrict__ Hs, float* __restrict__ vs, float* __restrict__ Eii,
+    float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz, int E, int HW, int wd) {
+  __shared__ float red[4];
+  const int e = blockIdx.x;
+  const int ix = (int)ii[e], jx = (int)jj[e];
+  const float fx = intrinsics[0], fy = intrinsics[1], cx = intrinsics[2], cy = intrinsics[3];
+  float tij[3], qij[4];
+  if (ix == jx) {  // stereo pair: fixed baseline (:218-229)
+    tij[0] = -0.1f; tij[1] = 0.f; tij[2] = 0.f;
+    qij[0] = 0.f; qij[1] = 0.f; qij[2] = 0.f; qij[3] = 1.f;
+  } else {
+    rel_se3(poses + ix * 7, poses + ix * 7 + 3, poses + jx * 7, poses + jx * 7 + 3, tij, qij);  // uniform: scalar math
+  }
+  float hij[78], vi[6], vj[6];
+#pragma unroll
+  for (int l = 0; l < 78; l++) hij[l] = 0.f;
+#pragma unroll
+  for (int n = 0; n < 6; n++) vi[n] = vj[n] = 0.f;
+  const size_t eo = (size_t)e * HW;
+  for (int k = threadIdx.x; k < HW; k += BA_THREADS) {
+    const int i = k / wd, j = k - i * wd;
+    float Xi[3] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.0f}, Xj[3];
+    const float h = disps[(size_t)ix * HW + k];
+    act_so3(qij, Xi, Xj);  // actSE3 :69-76
+    Xj[0] += h * tij[0]; Xj[1] += h * tij[1]; Xj[2] += h * tij[2];
+    const float x = Xj[0], y = Xj[1];
+    const bool ok = !(Xj[2] < BA_MIN_DEPTH);
+    const float d = ok ? 1.0f / Xj[2] : 0.0f, d2 = d * d;
+    float wu = ok ? .001f * weight[(eo * 2) + k] : 0.0f;
+    float wv = ok ? .001f * weight[(eo * 2) + HW + k] : 0.0f;
+    const float ru = target[(eo * 2) + k] - (fx * d * x + cx);
+    const float rv = target[(eo * 2) + HW + k] - (fy * d * y + cy);
+    float Jx[12];
+    float* const Ji = Jx;
+    float* const Jj = Jx + 6;
+    // x coordinate (:292-325)
+    Jj[0] = fx * (h * d); Jj[1] = fx * 0.f; Jj[2] = fx * (-x * h * d2);
+    Jj[3] = fx * (-x * y * d2); Jj[4] = fx * (1 + x * x * d2); Jj[5] = fx * (-y * d);
+    float Jz = fx * (tij[0] * d - tij[2] * (x * d2));
+    float cii = wu * Jz * Jz, b = wu * ru * Jz;
+    if (ix == jx) wu = 0.f;
+    adj_se3(tij, qij, Jj, Ji);
+#pragma unroll
+    for (int n = 0; n < 6; n++) Ji[n] = -Ji[n];
+    {
+      int l = 0;
+#pragma unroll
+      for (int n = 0; n < 12; n++)
+#pragma unroll
+        for (int m = 0; m <= n; m++) hij[l++] += wu * Jx[n] * Jx[m];
+    }
+    float ei[6], ej[6];
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+      vi[n] += wu * ru * Ji[n];
+      vj[n] += wu * ru * Jj[n];
+      ei[n] = wu * Jz * Ji[n];
+      ej[n] = wu * Jz * Jj[n];
+    }
+    // y coordinate (:328-365)
+    Jj[0] = fy * 0.f; Jj[1] = fy * (h * d); Jj[2] = fy * (-y * h * d2);
+    Jj[3] = fy * (-1 - y * y * d2); Jj[4] = fy * (x * y * d2); Jj[5] = fy * (x * d);
+    Jz = fy * (tij[1] * d - tij[2] * (y * d2));
+    cii += wv * Jz * Jz;
+    b += wv * rv * Jz;
+    if (ix == jx) wv = 0.f;
+    adj_se3(tij, qij, Jj, Ji);
+#pragma unroll
+    for (int n = 0; n < 6; n++) Ji[n] = -Ji[n];
+    {
+      int l = 0;
+#pragma unroll
+      for (int n = 0; n < 12; n++)
+#pragma unroll
+        for (int m = 0; m <= n; m++) hij[l++] += wv * Jx[n] * Jx[m];
+    }
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+      vi[n] += wv * rv * Ji[n];
+      vj[n] += wv * rv * Jj[n];
+      Eii[(eo * 6) + (size_t)n * HW + k] = ei[n] + wv * Jz * Ji[n];
+      Eij[(eo * 6) + (size_t)n * HW + k] = ej[n] + wv * Jz * Jj[n];
+    }
+    Cii[eo + k] = cii;
+    bz[eo + k] = b;
+  }
+  // block reductions (:369-424)
+#pragma unroll
+  for (int n = 0; n < 6; n++) {
+    const float a = block_sum(vi[n], red), c = block_sum(vj[n], red);
+    if (threadIdx.x == 0) {
+      vs[((size_t)0 * E + e) * 6 + n] = a;
+      vs[((size_t)1 * E + e) * 6 + n] = c;
+    }
+  }
+  {
+    int l = 0;
+#pragma unroll
+    for (int n = 0; n < 12; n++)
+#pragma unroll
+      for (int m = 0; m <= n; m++) {
+        const float s = block_sum(hij[l++], red);
+        if (threadIdx.x == 0) {
+          float* const H0 = Hs + ((size_t)0 * E + e) * 36, * const H1 = Hs + ((size_t)1 * E + e) * 36;
+          float* const H2 = Hs + ((size_t)2 * E + e) * 36, * const H3 = Hs + ((size_t)3 * E + e) * 36;
+          if (n < 6 && m < 6) { H0[n * 6 + m] = s; H0[m * 6 + n] = s; }
+          else if (n >= 6 && m < 6) { H1[m * 6 + (n - 6)] = s; H2[(n - 6) * 6 + m] = s; }
+          else { H3[(n - 6) * 6 + (m - 6)] = s; H3[(m - 6) * 6 + (n - 6)] = s; }
+        }
+      }
+  }
+}
+
+// ---- segment sums: out[j][:] = sum of inp[idxs[i]][:] for i in [ptrs[j], ptrs[j+1])  (:854-874) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_accum_kernel(const float* __restrict__ inp, const long long* __restrict__ ptrs,
+                                                              const long long* __restrict__ idxs, float* __restrict__ out, int D) {
+  const int start = (int)ptrs[blockIdx.x], end = (int)ptrs[blockIdx.x + 1];
+  for (int k = threadIdx.x; k < D; k += BA_THREADS) {
+    float x = 0.f;
+    for (int i = start; i < end; i++) x += inp[(size_t)idxs[i] * D + k];
+    out[(size_t)blockIdx.x * D + k] = x;
+  }
+}
+
+// ---- S[b] = (E[ix] * Q[kx]) E[jx]^T over the pixels (:1001-1056) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_eet_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
+                                                            const long long* __restrict__ idx, float* __restrict__ S, int D) {
+  __shared__ float red[4];
+  const int ix = (int)idx[blockIdx.x * 3 + 0], jx = (int)idx[blockIdx.x * 3 + 1], kx = (int)idx[blockIdx.x * 3 + 2];
+  float dS[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) dS[i] = 0.f;
+  for (int k = threadIdx.x; k < D; k += BA_THREADS) {
+    const float q = Q[(size_t)kx * D + k];
+    float ei[6], ej[6];
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+      ei[n] = Em[((size_t)ix * 6 + n) * D + k] * q;
+      ej[n] = Em[((size_t)jx * 6 + n) * D + k];
+    }
+#pragma unroll
+    for (int n = 0; n < 6; n++)
+#pragma unroll
+      for (int m = 0; m < 6; m++) dS[n * 6 + m] += ei[n] * ej[m];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; i++) {
+    const float s = block_sum(dS[i], red);
+    if (threadIdx.x == 0) S[(size_t)blockIdx.x * 36 + i] = s;
+  }
+}
+
+// ---- v[n] = E[n] (Q[k(n)] * w[k(n)])  (:1059-1093; v is written, the caller zero-initialises nothing) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_ev_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
+                                                           const float* __restrict__ w, const long long* __restrict__ kk,
+                                                           float* __restrict__ v, int D) {
+  __shared__ float red[4];
+  const int kx = (int)kk[blockIdx.x];
+  float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = threadIdx.x; k < D; k += BA_THREADS) {
+    const float qw = Q[(size_t)kx * D + k] * w[(size_t)kx * D + k];
+#pragma unroll
+    for (int n = 0; n < 6; n++) b[n] += qw * Em[((size_t)blockIdx.x * 6 + n) * D + k];
+  }
+#pragma unroll
+  for (int n = 0; n < 6; n++) {
+    const float s = block_sum(b[n], red);
+    if (threadIdx.x == 0) v[(size_t)blockIdx.x * 6 + n] = s;
+  }
+}
+
+// ---- dw[n][:] = E[n]^T x[idx[n]]; rows whose pose index is <= 0 or >= P stay zero (:1095-1115, sic) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_evt_kernel(const float* __restrict__ Em, const float* __restrict__ x,
+                                                            const long long* __restrict__ idx, float* __restrict__ dw, int D,
+                                                            int P) {
+  const int ix = (int)idx[blockIdx.x];
+  const bool skip = ix <= 0 || ix >= P;
+  float xr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (!skip)
+#pragma unroll
+    for (int n = 0; n < 6; n++) xr[n] = x[ix * 6 + n];
+  for (int k = threadIdx.x; k < D; k += BA_THREADS) {
+    float s = 0.f;
+    if (!skip)
+#pragma unroll
+      for (int n = 0; n < 6; n++) s += Em[((size_t)blockIdx.x * 6 + n) * D + k] * xr[n];
+    dw[(size_t)blockIdx.x * D + k] = s;
+  }
+}
+
+// ---- SE3 retraction of the poses t0 .. t1-1 (:877-931) ----
+__device__ __forceinline__ void exp_so3(const float* phi, float* q) {  // :110-131
+  const float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  const float theta_p4 = theta_sq * theta_sq, theta = sqrtf(theta_sq);
+  float imag, real;
+  if (theta_sq < 1e-8f) {
+    imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_p4;
+    real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_p4;
+  } else {
+    imag = sinf(0.5f * theta) / theta;
+    real = cosf(0.5f * theta);
+  }
+  q[0] = imag * phi[0]; q[1] = imag * phi[1]; q[2] = imag * phi[2]; q[3] = real;
+}
+__global__ void ba_pose_retr_kernel(float* poses, const float* __restrict__ dx, int t0, int t1) {
+  for (int k = t0 + blockIdx.x * blockDim.x + threadIdx.x; k < t1; k += gridDim.x * blockDim.x) {
+    float xi[6], t[3], q[4], dt[3], dq[4], t1v[3], q1[4];
+#pragma unroll
+    for (int n = 0; n < 6; n++) xi[n] = dx[(k - t0) * 6 + n];
+#pragma unroll
+    for (int n = 0; n < 3; n++) t[n] = poses[k * 7 + n];
+#pragma unroll
+    for (int n = 0; n < 4; n++) q[n] = poses[k * 7 + 3 + n];
+    // expSE3 :147-174
+    exp_so3(xi + 3, dq);
+    float tau[3] = {xi[0], xi[1], xi[2]}, tmp[3];
+    const float* phi = xi + 3;
+    const float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2], theta = sqrtf(theta_sq);
+    dt[0] = tau[0]; dt[1] = tau[1]; dt[2] = tau[2];
+    if (theta > 1e-4f) {
+      const float a = (1 - cosf(theta)) / theta_sq;
+      cross3(phi, tau, tmp); tau[0] = tmp[0]; tau[1] = tmp[1]; tau[2] = tmp[2];
+      dt[0] += a * tau[0]; dt[1] += a * tau[1]; dt[2] += a * tau[2];
+      const float b = (theta - sinf(theta)) / (theta * theta_sq);
+      cross3(phi, tau, tmp); tau[0] = tmp[0]; tau[1] = tmp[1]; tau[2] = tmp[2];
+      dt[0] += b * tau[0]; dt[1] += b * tau[1]; dt[2] += b * tau[2];
+    }
+    q1[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+    q1[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
+    q1[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
+    q1[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+    act_so3(dq, t, t1v);
+#pragma unroll
+    for (int n = 0; n < 3; n++) poses[k * 7 + n] = t1v[n] + dt[n];
+#pragma unroll
+    for (int n = 0; n < 4; n++) poses[k * 7 + 3 + n] = q1[n];
+  }
+}
+
+// ---- disps[inds[b]][:] += dz[b][:]  (:933-946) ----
+__global__ __launch_bounds__(BA_THREADS) void ba_disp_retr_kernel(float* disps, const float* __restrict__ dz,
+                                                                  const long long* __restrict__ inds, int HW) {
+  const size_t f = (size_t)inds[blockIdx.x];
+  for (int k = threadIdx.x; k < HW; k += BA_THREADS) disps[f * HW + k] += dz[(size_t)blockIdx.x * HW + k];
+}
+
+}  // namespace lgu
+
+extern "C" {
+
+int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
+                     const float* intrinsics, const long long* ii, const long long* jj, float* Hs, float* vs, float* Eii,
+                     float* Eij, float* Cii, float* wi, int E, int ht, int wd, void* stream) {
+  using namespace lgu;
+  if (!targets || !weights || !poses || !disps || !intrinsics || !ii || !jj || !Hs || !vs || !Eii || !Eij || !Cii || !wi)
+    return LGU_E_BADARG;
+  if (E < 0 || ht < 1 || wd < 1) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_build_kernel, dim3(E), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), targets, weights,
+                     poses, disps, intrinsics, ii, jj, Hs, vs, Eii, Eij, Cii, wi, E, ht * wd, wd);
+  return launch_status();
+}
+
+int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* idxs, float* out, int nout, int D, void* stream) {
+  using namespace lgu;
+  if (!inp || !ptrs || !out || nout < 0 || D < 1) return LGU_E_BADARG;
+  if (nout == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_accum_kernel, dim3(nout), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs,
+                     out, D);
+  return launch_status();
+}
+
+int lgu_ba_eet_f32(const float* Em, const float* Q, const long long* idx, float* S, int nblocks, int D, void* stream) {
+  using namespace lgu;
+  if (!Em || !Q || !S || nblocks < 0 || D < 1) return LGU_E_BADARG;
+  if (nblocks == 0) return LGU_OK;
+  if (!idx) return LGU_E_BADARG;
+  hipLaunchKernelGGL(ba_eet_kernel, dim3(nblocks), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), Em, Q, idx, S, D);
+  return launch_status();
+}
+
+int lgu_ba_ev_f32(const float* Em, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream) {
+  using namespace lgu;
+  if (!Em || !Q || !w || !kk || !v || n < 0 || D < 1) return LGU_E_BADARG;
+  if (n == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_ev_kernel, dim3(n), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), Em, Q, w, kk, v, D);
+  return launch_status();
+}
+
+int lgu_ba_evt_f32(const float* Em, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream) {
+  using namespace lgu;
+  if (!Em || !x || !idx || !dw || n < 0 || D < 1 || P < 1) return LGU_E_BADARG;
+  if (n == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_evt_kernel, dim3(n), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), Em, x, idx, dw, D, P);
+  return launch_status();
+}
+
+int lgu_ba_pose_retr_f32(float* poses, const float* dx, int t0, int t1, void* stream) {
+  using namespace lgu;
+  if (!poses || !dx || t0 < 0 || t1 < t0) return LGU_E_BADARG;
+  if (t1 == t0) return LGU_OK;
+  hipLaunchKernelGGL(ba_pose_retr_kernel, dim3((t1 - t0 + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), poses, dx,
+                     t0, t1);
+  return launch_status();
+}
+
+int lgu_ba_disp_retr_f32(float* disps, const float* dz, const long long* inds, int n, int HW, void* stream) {
+  using namespace lgu;
+  if (!disps || !dz || !inds || n < 0 || HW < 1) return LGU_E_BADARG;
+  if (n == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_disp_retr_kernel, dim3(n), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), disps, dz, inds, HW);
+  return launch_status();
+}
+
+}  // extern "C"
