@@ -32,17 +32,21 @@ def _segments(ix, jx):
     return ptrs, cols
 
 
-def _accum(lib, data, ix, jx, st):
-    """out[j] = sum of data[n] over ix[n] == jx[j] (accum_cuda :948-998); data (n, D) float32 on the device."""
-    dev = data.device
-    ptrs, cols = _segments(ix, jx)
-    out = torch.empty((len(jx), data.shape[1]), dtype=torch.float32, device=dev)
-    if len(jx) == 0:
+class _Accum:
+    """out[j] = sum of data[n] over ix[n] == jx[j] (accum_cuda :948-998); the segment tables are built once."""
+
+    def __init__(self, lib, ix, jx, dev):
+        ptrs, cols = _segments(ix, jx)
+        self.lib, self.n = lib, len(jx)
+        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+        self.cols = torch.tensor(cols if cols else [0], dtype=torch.int64, device=dev)
+
+    def __call__(self, data, st):
+        out = torch.empty((self.n, data.shape[1]), dtype=torch.float32, device=data.device)
+        if self.n:
+            _lib.check(self.lib.lgu_ba_accum_f32(_ptr(data), _ptr(self.ptrs), _ptr(self.cols), _ptr(out), self.n, data.shape[1], st),
+                       "ba accum")
         return out
-    p = torch.tensor(ptrs, dtype=torch.int64, device=dev)
-    c = torch.tensor(cols if cols else [0], dtype=torch.int64, device=dev)
-    _lib.check(lib.lgu_ba_accum_f32(_ptr(data), _ptr(p), _ptr(c), _ptr(out), len(jx), data.shape[1], st), "ba accum")
-    return out
 
 
 def _solve(A, b, lm, ep):
@@ -87,27 +91,27 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         vkeep = vi >= 0
         if not motion_only:
             # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
-            graph = [[] for _ in range(P)]
-            index = [[] for _ in range(P)]
+            # (grouped by depth frame: the same set of (n, m) pairs as the reference's P x P double loop, in O(pairs))
+            by_k = {}
             for n, (j, k) in enumerate(zip(jj_exp_h, kk_h)):
                 if t0 <= j < t1:
-                    graph[j - t0].append(k)
-                    index[j - t0].append(n)
+                    by_k.setdefault(k, []).append((j - t0, n))
             trip, pi, pj = [], [], []
-            for i in range(P):
-                for j in range(P):
-                    for a, ka in zip(index[i], graph[i]):
-                        for c, kc in zip(index[j], graph[j]):
-                            if ka == kc:
-                                trip += [a, c, ka]
-                                pi.append(i)
-                                pj.append(j)
+            for k, lst in by_k.items():
+                for ta, a in lst:
+                    for tc, c in lst:
+                        trip += [a, c, k]
+                        pi.append(ta)
+                        pj.append(tc)
             trip_t = torch.tensor(trip if trip else [0, 0, 0], dtype=torch.int64, device=dev).view(-1, 3)
             sflat = torch.tensor([a * P + b for a, b in zip(pi, pj)], dtype=torch.int64, device=dev)
             jpose = torch.tensor(jj_exp_h, dtype=torch.int64, device=dev) - t0
             jkeep = jpose >= 0
             m = (disps_sens[kx] > 0).to(f32).view(-1, HW)
             eta_v = eta.reshape(-1, HW).to(f32)
+            acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
+            acc_ii_ts = _Accum(lib, ii_h, ts_h, dev)
+            acc_exp_kx = _Accum(lib, ii_exp_h, kx_h, dev)
 
         Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
         vs = torch.empty((2, E, 6), dtype=f32, device=dev)
@@ -126,11 +130,11 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             b = torch.zeros((P, 6), dtype=f64, device=dev)
             b.index_add_(0, vi[vkeep], vs.view(-1, 6)[vkeep].to(f64))
             if not motion_only:
-                C = _accum(lib, Cii, ii_h, kx_h, st) + m * _ALPHA + (1 - m) * eta_v                       # :1396
-                w = _accum(lib, wi, ii_h, kx_h, st) - m * _ALPHA * (disps[kx] - disps_sens[kx]).view(-1, HW)   # :1397
+                C = acc_ii_kx(Cii, st) + m * _ALPHA + (1 - m) * eta_v                       # :1396
+                w = acc_ii_kx(wi, st) - m * _ALPHA * (disps[kx] - disps_sens[kx]).view(-1, HW)   # :1397
                 Q = (1.0 / C).contiguous()
                 w = w.contiguous()
-                Ei = _accum(lib, Eii.view(E, 6 * HW), ii_h, ts_h, st).view(P, 6, HW)                     # :1400
+                Ei = acc_ii_ts(Eii.view(E, 6 * HW), st).view(P, 6, HW)                     # :1400
                 Eall = torch.cat([Ei, Eij], 0).contiguous()                                             # :1401
                 nE = Eall.shape[0]
                 S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
@@ -145,7 +149,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             if not motion_only:
                 dw = torch.empty((nE, HW), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose.contiguous()), _ptr(dw), nE, HW, P, st), "ba EvT")
-                dz = (Q * (w - _accum(lib, dw, ii_exp_h, kx_h, st))).contiguous()                       # :1415
+                dz = (Q * (w - acc_exp_kx(dw, st))).contiguous()                       # :1415
             _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
             if not motion_only:
                 _lib.check(lib.lgu_ba_disp_retr_f32(_ptr(disps), _ptr(dz), _ptr(kx), kx.shape[0], HW, st), "ba disp retraction")

@@ -69,4 +69,25 @@ with torch.no_grad():
     cb = torch.stack([xsb, ysb], -1)[None, None] + 2 * torch.randn(1, 16, H, W, 2, device=dev)
     alt = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
     res["AltCorrBlock.__call__ 16 edges 60x80 half (offset convs + probe + fused launch)"] = wall(lambda: alt(cb, ii, jj), iters=20, warm=3)
+    # dense BA, frontend-sized window: 12 keyframes of 48x64, edges within 3 frames (66 edges), window [2, 12), 2 iterations
+    import numpy as np
+    N, h, w = 12, 48, 64
+    ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= 3]
+    jj_l = [j for i in range(N) for j in range(N) if i != j and abs(i - j) <= 3]
+    iib, jjb = torch.tensor(ii_l, device=dev), torch.tensor(jj_l, device=dev)
+    poses = torch.zeros(N, 7, device=dev)
+    poses[:, 6] = 1
+    poses[:, 0] = torch.arange(N, device=dev) * 0.05
+    disps = 0.3 + 0.7 * torch.rand(N, h, w, device=dev)
+    intr = torch.tensor([50.0, 50.0, 32.0, 24.0], device=dev)
+    ys2, xs2 = torch.meshgrid(torch.arange(h, device=dev).float(), torch.arange(w, device=dev).float(), indexing="ij")
+    tgt = torch.stack([xs2, ys2])[None].repeat(len(ii_l), 1, 1, 1) + torch.randn(len(ii_l), 2, h, w, device=dev)
+    wgt = torch.rand(len(ii_l), 2, h, w, device=dev)
+    eta = torch.full((N, h, w), 1e-3, device=dev)
+    sens = torch.zeros_like(disps)
+
+    def run_ba():
+        lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, iib, jjb, 2, N, 2, 1e-4, 0.1, False)
+
+    res["ba: 12 keyframes 48x64, %d edges, 2 iterations (ms, wall incl. host bookkeeping)" % len(ii_l)] = wall(run_ba, iters=10, warm=2)
 print(json.dumps(res, indent=1))
