@@ -153,3 +153,20 @@ def test_hip_ba_converges_on_a_frontend_sized_window(lgu):
     lgu.ba.ba(pd, dd, idv, sd, td, wd_, ed, iid, jjd, 2, len(p), 6, 1e-4, 1e-6, False)
     c1 = cost(pd.cpu().numpy(), dd.cpu().numpy(), intr, ii, jj, targets)
     assert c1 < 1e-6 * c0
+
+
+@pytest.mark.gpu
+def test_hip_ba_larger_graph_with_fixed_source_frames(lgu):
+    """40 frames, ~230 edges, window [5, 40): edges whose source or target frame lies before t0 contribute to the
+    depth / pose blocks they touch but get no pose update of their own (update_lhs / update_rhs skip negative block
+    indices); device result against the oracle."""
+    rng, intr, poses, disps, ii, jj, targets = scene(11, N=40, H=8, W=12, span=3)
+    t0 = 5
+    p, d = perturb(rng, poses, disps, t0)
+    weights = (0.5 + rng.random(targets.shape)).astype(f32)
+    eta = np.full(d.shape, 1e-3, f32)
+    (po, do, dxo, dzo), (pd, dd, dxd, dzd) = _run_both(lgu, p, d, intr, np.zeros_like(d), targets, weights, eta, ii, jj, t0, len(p), 1,
+                                                       1e-4, 0.1, False)
+    assert np.abs(dxd - dxo).max() <= 5e-4 * np.abs(dxo).max() + 1e-7
+    assert np.abs(dzd - dzo).max() <= 5e-4 * np.abs(dzo).max() + 1e-7
+    assert np.array_equal(pd[:t0], p[:t0]) and np.abs(pd - po).max() <= 5e-4 * np.abs(po - p).max() + 1e-6
