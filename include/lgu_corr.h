@@ -227,6 +227,10 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  * lgu_ba_ev_f32           Ev6x1_kernel (:1059-1093): v[n] = E[n] (Q[kk[n]] * w[kk[n]]), fully written.
  * lgu_ba_evt_f32          EvT6x1_kernel (:1095-1115): dw[n] = E[n]^T x[idx[n]], zero rows where idx[n] <= 0 or >= P
  *                         (the reference's condition, kept).
+ * lgu_ba_solve_f64        SparseBlock::solve (:1206-1231), which the reference runs on the CPU with Eigen: damping
+ *                         diag += ep + lm*diag, blocked Cholesky and both triangular solves in one workgroup with the
+ *                         matrix in LDS.  A (6P x 6P, row-major double, symmetric), b (6P) double; x (P,6) float; x = 0
+ *                         if the damped matrix is not positive definite.  6P <= 126, otherwise LGU_E_UNSUPPORTED.
  * lgu_ba_pose_retr_f32    pose_retr_kernel (:898-931): poses[k] <- exp(dx[k-t0]) * poses[k], k in [t0, t1).
  * lgu_ba_disp_retr_f32    disp_retr_kernel (:933-946): disps[inds[b]] += dz[b]. */
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
@@ -237,6 +241,7 @@ int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* i
 int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* S, int nblocks, int D, void* stream);
 int lgu_ba_ev_f32(const float* E, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream);
 int lgu_ba_evt_f32(const float* E, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream);
+int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double lm, double ep, void* stream);
 int lgu_ba_pose_retr_f32(float* poses, const float* dx, int t0, int t1, void* stream);
 int lgu_ba_disp_retr_f32(float* disps, const float* dz, const long long* inds, int n, int HW, void* stream);
 

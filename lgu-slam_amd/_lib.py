@@ -41,6 +41,7 @@ SIGNATURES = {
     "lgu_ba_eet_f32": [_vp] * 4 + [_int] * 2 + [_vp],
     "lgu_ba_ev_f32": [_vp] * 5 + [_int] * 2 + [_vp],
     "lgu_ba_evt_f32": [_vp] * 4 + [_int] * 3 + [_vp],
+    "lgu_ba_solve_f64": [_vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _vp],
     "lgu_ba_pose_retr_f32": [_vp] * 2 + [_int] * 2 + [_vp],
     "lgu_ba_disp_retr_f32": [_vp] * 3 + [_int] * 2 + [_vp],
     "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],

@@ -144,8 +144,13 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                 sv = torch.empty((nE, 6), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
                 b.index_add_(0, jpose[jkeep], -sv[jkeep].to(f64))
-            Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P)
-            dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+            Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
+            dx = torch.empty((P, 6), dtype=f32, device=dev)
+            rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
+            if rc == _lib.LGU_E_UNSUPPORTED:   # more than 21 poses in the window: library Cholesky on the device
+                dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+            else:
+                _lib.check(rc, "ba solve")
             if not motion_only:
                 dw = torch.empty((nE, HW), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose.contiguous()), _ptr(dw), nE, HW, P, st), "ba EvT")

@@ -312,9 +312,100 @@ __global__ __launch_bounds__(BA_THREADS) void ba_disp_retr_kernel(float* disps, 
   for (int k = threadIdx.x; k < HW; k += BA_THREADS) disps[f * HW + k] += dz[(size_t)blockIdx.x * HW + k];
 }
 
+// ---- reduced camera system: damping + blocked Cholesky + solve in ONE workgroup (SparseBlock::solve :1206-1231) ----
+// A (n x n, n = 6 P, row-major double, symmetric) and b (n) stay untouched; x (P,6) float.  The matrix lives in LDS
+// (n <= 126: 127 KB), factorised by 6 x 6 block columns: diagonal block by one thread, panel solve with lanes over
+// rows, trailing update with lanes over (row, column-block) pairs; then the two triangular solves.  Not positive
+// definite (a pivot <= 0 or not finite): x = 0, as the reference does when Eigen reports failure.
+constexpr int BA_SOLVE_MAXN = 126;
+__global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __restrict__ A, const double* __restrict__ b,
+                                                              float* __restrict__ x, int n, double lm, double ep) {
+  extern __shared__ double Ls[];  // [n][n + 1] lower triangle used, then [n] rhs
+  const int ld = n + 1;
+  double* const y = Ls + (size_t)n * ld;
+  int& bad = *reinterpret_cast<int*>(y + n);
+  if (threadIdx.x == 0) bad = 0;
+  for (int idx = threadIdx.x; idx < n * n; idx += BA_THREADS) {
+    const int i = idx / n, j = idx - i * n;
+    double v = A[idx];
+    if (i == j) v += ep + lm * v;  // L.diagonal() += ep + lm * L.diagonal()
+    Ls[i * ld + j] = v;
+  }
+  for (int i = threadIdx.x; i < n; i += BA_THREADS) y[i] = b[i];
+  __syncthreads();
+  const int nb = n / 6;
+  for (int kb = 0; kb < nb; kb++) {
+    const int k0 = kb * 6;
+    if (threadIdx.x == 0) {  // 6 x 6 diagonal block
+      for (int k = k0; k < k0 + 6; k++) {
+        double d = Ls[k * ld + k];
+        for (int p = k0; p < k; p++) d -= Ls[k * ld + p] * Ls[k * ld + p];
+        if (!(d > 0.0) || !(d < 1e300)) { bad = 1; d = 1.0; }
+        d = sqrt(d);
+        Ls[k * ld + k] = d;
+        for (int i = k + 1; i < k0 + 6; i++) {
+          double v = Ls[i * ld + k];
+          for (int p = k0; p < k; p++) v -= Ls[i * ld + p] * Ls[k * ld + p];
+          Ls[i * ld + k] = v / d;
+        }
+      }
+    }
+    __syncthreads();
+    // panel: rows below the block solve L_ik L_kk^T = A_ik
+    for (int i = k0 + 6 + threadIdx.x; i < n; i += BA_THREADS) {
+      for (int k = k0; k < k0 + 6; k++) {
+        double v = Ls[i * ld + k];
+        for (int p = k0; p < k; p++) v -= Ls[i * ld + p] * Ls[k * ld + p];
+        Ls[i * ld + k] = v / Ls[k * ld + k];
+      }
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: A_ij -= L_i,kb L_j,kb^T for j <= i, both below the block
+    const int m = n - (k0 + 6);
+    for (int idx = threadIdx.x; idx < m * m; idx += BA_THREADS) {
+      const int i = k0 + 6 + idx / m, j = k0 + 6 + idx % m;
+      if (j > i) continue;
+      double v = 0.0;
+#pragma unroll
+      for (int p = 0; p < 6; p++) v += Ls[i * ld + k0 + p] * Ls[j * ld + k0 + p];
+      Ls[i * ld + j] -= v;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && !bad) {  // L y = b, L^T x = y (n <= 126: a few thousand operations)
+    for (int i = 0; i < n; i++) {
+      double v = y[i];
+      for (int p = 0; p < i; p++) v -= Ls[i * ld + p] * y[p];
+      y[i] = v / Ls[i * ld + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double v = y[i];
+      for (int p = i + 1; p < n; p++) v -= Ls[p * ld + i] * y[p];
+      y[i] = v / Ls[i * ld + i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += BA_THREADS) x[i] = bad ? 0.0f : (float)y[i];
+}
+
 }  // namespace lgu
 
 extern "C" {
+
+int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double lm, double ep, void* stream) {
+  using namespace lgu;
+  if (!A || !b || !x || P < 1) return LGU_E_BADARG;
+  const int n = 6 * P;
+  if (n > BA_SOLVE_MAXN) return LGU_E_UNSUPPORTED;  // larger systems: the caller uses a library factorisation
+  const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + n + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_THREADS), lds, reinterpret_cast<hipStream_t>(stream), A, b, x, n, lm, ep);
+  return launch_status();
+}
 
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
                      const float* intrinsics, const long long* ii, const long long* jj, float* Hs, float* vs, float* Eii,
