@@ -150,3 +150,16 @@ class ShardedAltCorr:
         for idx in self.edges.my_chunks:
             iis, jjs = self.ii[idx], self.jj[idx]
             yield idx, self.block(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long())
+
+
+def sharded_ba(edges, target_local, weight_local, poses, disps, intrinsics, disps_sens, eta, ii, jj, t0, t1,
+               iterations, lm, ep, motion_only):
+    """The dense-BA step of a sharded update (reference factor_graph.py:290-300 after update_lowmem's chunk loop):
+    every rank contributes the `target` / `weight` (n_local,2,ht,wd) of the edges it owns (in `edges.my_edges`
+    order); ONE all-gather each restores the full (E,2,ht,wd) tensors in the original edge order on every rank, and the
+    bundle adjustment (lgu_slam_amd.ba.ba) then runs replicated — identical inputs, deterministic kernels, so every
+    rank holds the same updated `poses` / `disps` without a broadcast."""
+    from . import ba as _ba
+    target = edges.gather(target_local).contiguous()
+    weight = edges.gather(weight_local).contiguous()
+    return _ba.ba(poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only)

@@ -170,3 +170,25 @@ def test_hip_ba_larger_graph_with_fixed_source_frames(lgu):
     assert np.abs(dxd - dxo).max() <= 5e-4 * np.abs(dxo).max() + 1e-7
     assert np.abs(dzd - dzo).max() <= 5e-4 * np.abs(dzo).max() + 1e-7
     assert np.array_equal(pd[:t0], p[:t0]) and np.abs(pd - po).max() <= 5e-4 * np.abs(po - p).max() + 1e-6
+
+
+@pytest.mark.gpu
+def test_sharded_ba_world1_equals_plain_ba(lgu):
+    """sharded.sharded_ba at world size 1: per-edge target / weight handed over in the owner's chunk order come back in
+    the original edge order and the replicated BA equals the plain call bit for bit."""
+    rng, intr, poses, disps, ii, jj, targets = scene(13, N=12, H=8, W=12, span=2)
+    p, d = perturb(rng, poses, disps, 1)
+    weights = (0.5 + rng.random(targets.shape)).astype(f32)
+    eta = np.full(d.shape, 1e-3, f32)
+    iid, jjd = _to_dev(ii.astype(np.int64), jj.astype(np.int64))
+    edges = lgu.sharded.ShardedEdgeSet(iid, rank=0, world=1, chunk=4)
+    own = edges.my_edges.cpu().numpy()
+    assert not np.array_equal(own, np.arange(len(ii))) or len(own) == len(ii)
+    args = _to_dev(intr, np.zeros_like(d))
+    td, wd_, ed = _to_dev(targets, weights, eta)
+    p1, d1 = _to_dev(p, d)
+    p2, d2 = _to_dev(p, d)
+    a = lgu.ba.ba(p1, d1, args[0], args[1], td, wd_, ed, iid, jjd, 1, len(p), 2, 1e-4, 0.1, False)
+    b = lgu.sharded.sharded_ba(edges, td[edges.my_edges].contiguous(), wd_[edges.my_edges].contiguous(), p2, d2, args[0], args[1], ed,
+                               iid, jjd, 1, len(p), 2, 1e-4, 0.1, False)
+    assert torch.equal(p1, p2) and torch.equal(d1, d2) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
