@@ -223,6 +223,9 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  *   targets (E,2,ht,wd) with weights (E,2,ht,wd), pose / depth Jacobians; Hs (4,E,6,6) = Hii,Hij,Hji,Hjj, vs (2,E,6),
  *   Eii, Eij (E,6,ht*wd), Cii, wi (E,ht*wd), all fully written.  poses (N,7) = t, q(xyzw); disps (N,ht,wd); intrinsics (4).
  * lgu_ba_accum_f32        accum_kernel (:854-874): out[j] = sum of inp rows idxs[ptrs[j] .. ptrs[j+1]), rows of D floats.
+ * lgu_ba_scatter_sum_f64  assembly of the reduced camera system (SparseBlock::update_lhs / update_rhs :1137-1179, on the CPU
+ *                         in the reference): out[dst[j]] += sign * sum of inp rows idxs[ptrs[j] .. ptrs[j+1]) in double, rows of
+ *                         D floats; one thread per output component, fixed summation order (bit-reproducible).
  * lgu_ba_eet_f32          EEt6x6_kernel (:1001-1056): S[b] = (E[idx[b][0]] * Q[idx[b][2]]) E[idx[b][1]]^T, idx (nblocks,3).
  * lgu_ba_ev_f32           Ev6x1_kernel (:1059-1093): v[n] = E[n] (Q[kk[n]] * w[kk[n]]), fully written.
  * lgu_ba_evt_f32          EvT6x1_kernel (:1095-1115): dw[n] = E[n]^T x[idx[n]], zero rows where idx[n] <= 0 or >= P
@@ -238,6 +241,8 @@ int lgu_ba_build_f32(const float* targets, const float* weights, const float* po
                      float* Hs, float* vs, float* Eii, float* Eij, float* Cii, float* wi,
                      int E, int ht, int wd, void* stream);
 int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* idxs, float* out, int nout, int D, void* stream);
+int lgu_ba_scatter_sum_f64(const float* inp, const long long* ptrs, const long long* idxs, const long long* dst, double* out,
+                           int m, int D, double sign, void* stream);
 int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* S, int nblocks, int D, void* stream);
 int lgu_ba_ev_f32(const float* E, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream);
 int lgu_ba_evt_f32(const float* E, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream);

@@ -4,8 +4,8 @@
 Same signature, same in-place updates of `poses` and `disps`, same return value `[dx, dz]`.  What differs is the
 host side: the reference copies every 6x6 block to the CPU, assembles an Eigen sparse matrix in double and solves with
 SimplicialLLT once per iteration (host round trips inside the loop); here the reduced camera system is assembled
-(index_add on a dense (6P)^2 double matrix), damped and solved by Cholesky on the device — the data-parallel operands
-come from the HIP kernels of csrc/ba.hip.  The only host work is the graph bookkeeping (which E blocks meet in which
+(a dense (6P)^2 double matrix, summed in a fixed order so that replicated runs agree bit for bit), damped and solved
+by Cholesky on the device — every stage is a HIP kernel of csrc/ba.hip.  The only host work is the graph bookkeeping (which E blocks meet in which
 depth frame), built once per call from ii / jj exactly as the reference's schur_block / accum_cuda do on the CPU.
 
 PARITY UNPINNED (the reference needs Eigen, absent in this image): checked against oracle/ba_oracle.py, which is itself
@@ -49,6 +49,32 @@ class _Accum:
         return out
 
 
+class _ScatterSum:
+    """Deterministic `out[dst] += sign * sum(rows)` in double (lgu_ba_scatter_sum_f64): `dest[n]` = destination row of
+    input row n, or negative to drop it.  Tables built once per call; rows are summed in input order."""
+
+    def __init__(self, lib, dest, dev):
+        groups = {}
+        for n, d in enumerate(dest):
+            if d >= 0:
+                groups.setdefault(d, []).append(n)
+        keys = sorted(groups)
+        ptrs, idxs = [0], []
+        for k in keys:
+            idxs += groups[k]
+            ptrs.append(len(idxs))
+        self.lib, self.m = lib, len(keys)
+        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+        self.idxs = torch.tensor(idxs if idxs else [0], dtype=torch.int64, device=dev)
+        self.dst = torch.tensor(keys if keys else [0], dtype=torch.int64, device=dev)
+
+    def __call__(self, inp, out, sign, st):
+        if self.m:
+            D = inp.shape[1]
+            _lib.check(self.lib.lgu_ba_scatter_sum_f64(_ptr(inp), _ptr(self.ptrs), _ptr(self.idxs), _ptr(self.dst), _ptr(out), self.m, D,
+                                                       float(sign), st), "ba assembly")
+
+
 def _solve(A, b, lm, ep):
     """SparseBlock::solve (:1206-1231): (A + diag(ep + lm * diag A)) x = b by Cholesky in double; zeros if not SPD."""
     L = A.clone()
@@ -83,12 +109,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         kx = torch.tensor(kx_h, dtype=torch.int64, device=dev)
         kk = torch.tensor(kk_h, dtype=torch.int64, device=dev)
         # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
-        bi = torch.cat([ii, ii, jj, jj]) - t0
-        bj = torch.cat([ii, jj, ii, jj]) - t0
-        keep = (bi >= 0) & (bj >= 0)
-        flat = (bi * P + bj)[keep]
-        vi = torch.cat([ii, jj]) - t0
-        vkeep = vi >= 0
+        bi_h = [v - t0 for v in ii_h + ii_h + jj_h + jj_h]
+        bj_h = [v - t0 for v in ii_h + jj_h + ii_h + jj_h]
+        asm_H = _ScatterSum(lib, [a * P + c if (a >= 0 and c >= 0) else -1 for a, c in zip(bi_h, bj_h)], dev)
+        asm_v = _ScatterSum(lib, [v - t0 for v in ii_h + jj_h], dev)
         if not motion_only:
             # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
             # (grouped by depth frame: the same set of (n, m) pairs as the reference's P x P double loop, in O(pairs))
@@ -104,9 +128,9 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                         pi.append(ta)
                         pj.append(tc)
             trip_t = torch.tensor(trip if trip else [0, 0, 0], dtype=torch.int64, device=dev).view(-1, 3)
-            sflat = torch.tensor([a * P + b for a, b in zip(pi, pj)], dtype=torch.int64, device=dev)
+            asm_S = _ScatterSum(lib, [a * P + c for a, c in zip(pi, pj)], dev)
+            asm_sv = _ScatterSum(lib, [v - t0 for v in jj_exp_h], dev)
             jpose = torch.tensor(jj_exp_h, dtype=torch.int64, device=dev) - t0
-            jkeep = jpose >= 0
             m = (disps_sens[kx] > 0).to(f32).view(-1, HW)
             eta_v = eta.reshape(-1, HW).to(f32)
             acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
@@ -125,10 +149,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
                                             _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), E, ht, wd, st),
                        "ba build")
-            A = torch.zeros((P * P, 6, 6), dtype=f64, device=dev)
-            A.index_add_(0, flat, Hs.view(-1, 6, 6)[keep].to(f64))
+            A = torch.zeros((P * P, 36), dtype=f64, device=dev)
+            asm_H(Hs.view(-1, 36), A, 1.0, st)
             b = torch.zeros((P, 6), dtype=f64, device=dev)
-            b.index_add_(0, vi[vkeep], vs.view(-1, 6)[vkeep].to(f64))
+            asm_v(vs.view(-1, 6), b, 1.0, st)
             if not motion_only:
                 C = acc_ii_kx(Cii, st) + m * _ALPHA + (1 - m) * eta_v                       # :1396
                 w = acc_ii_kx(wi, st) - m * _ALPHA * (disps[kx] - disps_sens[kx]).view(-1, HW)   # :1397
@@ -140,10 +164,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                 S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
                 if trip:
                     _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
-                    A.index_add_(0, sflat, -S.to(f64))
+                    asm_S(S.view(-1, 36), A, -1.0, st)
                 sv = torch.empty((nE, 6), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
-                b.index_add_(0, jpose[jkeep], -sv[jkeep].to(f64))
+                asm_sv(sv, b, -1.0, st)
             Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
             dx = torch.empty((P, 6), dtype=f32, device=dev)
             rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS

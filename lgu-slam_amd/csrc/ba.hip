@@ -190,6 +190,20 @@ __global__ __launch_bounds__(BA_THREADS) void ba_accum_kernel(const float* __res
   }
 }
 
+// ---- deterministic assembly: out[dst[j]][:] += sign * sum of inp[idxs[i]][:], i in [ptrs[j], ptrs[j+1]), in double.
+// One thread per (destination, component), rows summed in table order: the replicated BA of a sharded run must
+// produce the same bits on every rank, which atomics-based index_add would not guarantee.
+__global__ __launch_bounds__(BA_THREADS) void ba_scatter_sum_kernel(const float* __restrict__ inp, const long long* __restrict__ ptrs,
+                                                                    const long long* __restrict__ idxs, const long long* __restrict__ dst,
+                                                                    double* __restrict__ out, int m, int D, double sign) {
+  const int t = blockIdx.x * BA_THREADS + threadIdx.x;
+  if (t >= m * D) return;
+  const int j = t / D, k = t - j * D;
+  double acc = 0.0;
+  for (long long i = ptrs[j]; i < ptrs[j + 1]; i++) acc += (double)inp[(size_t)idxs[i] * D + k];
+  out[(size_t)dst[j] * D + k] += sign * acc;
+}
+
 // ---- S[b] = (E[ix] * Q[kx]) E[jx]^T over the pixels (:1001-1056) ----
 __global__ __launch_bounds__(BA_THREADS) void ba_eet_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
                                                             const long long* __restrict__ idx, float* __restrict__ S, int D) {
@@ -426,6 +440,17 @@ int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* i
   if (nout == 0) return LGU_OK;
   hipLaunchKernelGGL(ba_accum_kernel, dim3(nout), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs,
                      out, D);
+  return launch_status();
+}
+
+int lgu_ba_scatter_sum_f64(const float* inp, const long long* ptrs, const long long* idxs, const long long* dst, double* out, int m,
+                           int D, double sign, void* stream) {
+  using namespace lgu;
+  if (!inp || !ptrs || !idxs || !dst || !out || m < 0 || D < 1) return LGU_E_BADARG;
+  if (m == 0) return LGU_OK;
+  const unsigned grid = (unsigned)(((size_t)m * D + BA_THREADS - 1) / BA_THREADS);
+  hipLaunchKernelGGL(ba_scatter_sum_kernel, dim3(grid), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs,
+                     dst, out, m, D, sign);
   return launch_status();
 }
 

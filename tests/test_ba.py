@@ -192,3 +192,18 @@ def test_sharded_ba_world1_equals_plain_ba(lgu):
     b = lgu.sharded.sharded_ba(edges, td[edges.my_edges].contiguous(), wd_[edges.my_edges].contiguous(), p2, d2, args[0], args[1], ed,
                                iid, jjd, 1, len(p), 2, 1e-4, 0.1, False)
     assert torch.equal(p1, p2) and torch.equal(d1, d2) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_hip_ba_is_bit_reproducible(lgu):
+    """Replicated BA on every rank of a sharded run must give the same bits: two runs from the same state are identical
+    (fixed-order block reductions and assembly, no atomics)."""
+    rng, intr, poses, disps, ii, jj, targets = scene(19, N=10, H=12, W=16, span=3)
+    p, d = perturb(rng, poses, disps, 1)
+    outs = []
+    for _ in range(2):
+        pd, dd, idv, sd, td, wd_, ed = _to_dev(p, d, intr, np.zeros_like(d), targets, np.ones_like(targets), np.full(d.shape, 1e-3, f32))
+        iid, jjd = _to_dev(ii.astype(np.int64), jj.astype(np.int64))
+        dx, dz = lgu.ba.ba(pd, dd, idv, sd, td, wd_, ed, iid, jjd, 1, len(p), 3, 1e-4, 0.1, False)
+        outs.append((pd.clone(), dd.clone(), dx.clone(), dz.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
