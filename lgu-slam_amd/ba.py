@@ -11,6 +11,7 @@ depth frame), built once per call from ii / jj exactly as the reference's schur_
 PARITY UNPINNED (the reference needs Eigen, absent in this image): checked against oracle/ba_oracle.py, which is itself
 pinned only by self-consistency tests (tests/test_ba.py).
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -20,15 +21,16 @@ _ALPHA = 0.05  # droid_kernels.cu:1394
 
 
 def _segments(ix, jx):
-    """accum_cuda's bookkeeping (:948-982): for every j, the rows n with ix[n] == jx[j]."""
-    order = sorted(range(len(ix)), key=lambda n: ix[n])
-    ptrs, cols, i = [0], [], 0
-    for j in jx:
-        while i < len(order) and ix[order[i]] <= j:
-            if ix[order[i]] == j:
-                cols.append(order[i])
-            i += 1
-        ptrs.append(len(cols))
+    """accum_cuda's bookkeeping (:948-982): for every j, the rows n with ix[n] == jx[j] (rows in ascending n)."""
+    ix = np.asarray(ix, dtype=np.int64)
+    jx = np.asarray(jx, dtype=np.int64)
+    order = np.argsort(ix, kind="stable")
+    sx = ix[order]
+    lo = np.searchsorted(sx, jx, side="left")
+    hi = np.searchsorted(sx, jx, side="right")
+    cnt = hi - lo
+    ptrs = np.concatenate([[0], np.cumsum(cnt)])
+    cols = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(jx) and cnt.sum() else np.zeros(0, np.int64)
     return ptrs, cols
 
 
@@ -38,8 +40,8 @@ class _Accum:
     def __init__(self, lib, ix, jx, dev):
         ptrs, cols = _segments(ix, jx)
         self.lib, self.n = lib, len(jx)
-        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
-        self.cols = torch.tensor(cols if cols else [0], dtype=torch.int64, device=dev)
+        self.ptrs = torch.from_numpy(np.ascontiguousarray(ptrs, dtype=np.int64)).to(dev)
+        self.cols = torch.from_numpy(np.ascontiguousarray(cols if len(cols) else [0], dtype=np.int64)).to(dev)
 
     def __call__(self, data, st):
         out = torch.empty((self.n, data.shape[1]), dtype=torch.float32, device=data.device)
@@ -54,19 +56,15 @@ class _ScatterSum:
     input row n, or negative to drop it.  Tables built once per call; rows are summed in input order."""
 
     def __init__(self, lib, dest, dev):
-        groups = {}
-        for n, d in enumerate(dest):
-            if d >= 0:
-                groups.setdefault(d, []).append(n)
-        keys = sorted(groups)
-        ptrs, idxs = [0], []
-        for k in keys:
-            idxs += groups[k]
-            ptrs.append(len(idxs))
+        dest = np.asarray(dest, dtype=np.int64)
+        rows = np.nonzero(dest >= 0)[0]
+        order = rows[np.argsort(dest[rows], kind="stable")]          # rows grouped by destination, ascending row inside
+        keys, counts = np.unique(dest[order], return_counts=True)
+        ptrs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         self.lib, self.m = lib, len(keys)
-        self.ptrs = torch.tensor(ptrs, dtype=torch.int64, device=dev)
-        self.idxs = torch.tensor(idxs if idxs else [0], dtype=torch.int64, device=dev)
-        self.dst = torch.tensor(keys if keys else [0], dtype=torch.int64, device=dev)
+        self.ptrs = torch.from_numpy(ptrs).to(dev)
+        self.idxs = torch.from_numpy(np.ascontiguousarray(order if len(order) else [0], dtype=np.int64)).to(dev)
+        self.dst = torch.from_numpy(np.ascontiguousarray(keys if len(keys) else [0], dtype=np.int64)).to(dev)
 
     def __call__(self, inp, out, sign, st):
         if self.m:
@@ -100,37 +98,39 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     f32, f64 = torch.float32, torch.float64
     with torch.cuda.device(dev):
         st = _stream(poses)
-        ii_h, jj_h = ii.tolist(), jj.tolist()     # graph bookkeeping on the host, once per call
-        ts_h = list(range(t0, t1))
-        ii_exp_h, jj_exp_h = ts_h + ii_h, ts_h + jj_h
-        kx_h = sorted(set(ii_exp_h))
-        kpos = {f: n for n, f in enumerate(kx_h)}
-        kk_h = [kpos[f] for f in ii_exp_h]
-        kx = torch.tensor(kx_h, dtype=torch.int64, device=dev)
-        kk = torch.tensor(kk_h, dtype=torch.int64, device=dev)
+        # graph bookkeeping on the host (numpy), once per call
+        ii_h, jj_h = ii.cpu().numpy().astype(np.int64), jj.cpu().numpy().astype(np.int64)
+        ts_h = np.arange(t0, t1, dtype=np.int64)
+        ii_exp_h, jj_exp_h = np.concatenate([ts_h, ii_h]), np.concatenate([ts_h, jj_h])
+        kx_h, kk_h = np.unique(ii_exp_h, return_inverse=True)           # :1340-1344
+        kk_h = kk_h.astype(np.int64)
+        kx = torch.from_numpy(kx_h).to(dev)
+        kk = torch.from_numpy(kk_h).to(dev)
         # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
-        bi_h = [v - t0 for v in ii_h + ii_h + jj_h + jj_h]
-        bj_h = [v - t0 for v in ii_h + jj_h + ii_h + jj_h]
-        asm_H = _ScatterSum(lib, [a * P + c if (a >= 0 and c >= 0) else -1 for a, c in zip(bi_h, bj_h)], dev)
-        asm_v = _ScatterSum(lib, [v - t0 for v in ii_h + jj_h], dev)
+        bi_h = np.concatenate([ii_h, ii_h, jj_h, jj_h]) - t0
+        bj_h = np.concatenate([ii_h, jj_h, ii_h, jj_h]) - t0
+        asm_H = _ScatterSum(lib, np.where((bi_h >= 0) & (bj_h >= 0), bi_h * P + bj_h, -1), dev)
+        asm_v = _ScatterSum(lib, np.concatenate([ii_h, jj_h]) - t0, dev)
         if not motion_only:
             # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
             # (grouped by depth frame: the same set of (n, m) pairs as the reference's P x P double loop, in O(pairs))
-            by_k = {}
-            for n, (j, k) in enumerate(zip(jj_exp_h, kk_h)):
-                if t0 <= j < t1:
-                    by_k.setdefault(k, []).append((j - t0, n))
-            trip, pi, pj = [], [], []
-            for k, lst in by_k.items():
-                for ta, a in lst:
-                    for tc, c in lst:
-                        trip += [a, c, k]
-                        pi.append(ta)
-                        pj.append(tc)
-            trip_t = torch.tensor(trip if trip else [0, 0, 0], dtype=torch.int64, device=dev).view(-1, 3)
-            asm_S = _ScatterSum(lib, [a * P + c for a, c in zip(pi, pj)], dev)
-            asm_sv = _ScatterSum(lib, [v - t0 for v in jj_exp_h], dev)
-            jpose = torch.tensor(jj_exp_h, dtype=torch.int64, device=dev) - t0
+            ent = np.nonzero((jj_exp_h >= t0) & (jj_exp_h < t1))[0]
+            ent = ent[np.argsort(kk_h[ent], kind="stable")]
+            _, starts, sizes = np.unique(kk_h[ent], return_index=True, return_counts=True)
+            a_l, c_l, k_l = [], [], []
+            for s0, m_ in zip(starts, sizes):                      # one small outer product per depth frame
+                g = ent[s0:s0 + m_]
+                a_l.append(np.repeat(g, m_)); c_l.append(np.tile(g, m_))
+                k_l.append(np.full(m_ * m_, kk_h[g[0]], np.int64))
+            have_pairs = len(a_l) > 0
+            if have_pairs:
+                a_n, c_n, k_n = np.concatenate(a_l), np.concatenate(c_l), np.concatenate(k_l)
+            else:
+                a_n = c_n = k_n = np.zeros(1, np.int64)
+            trip_t = torch.from_numpy(np.ascontiguousarray(np.stack([a_n, c_n, k_n], 1))).to(dev)
+            asm_S = _ScatterSum(lib, (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0) if have_pairs else np.zeros(0, np.int64), dev)
+            asm_sv = _ScatterSum(lib, jj_exp_h - t0, dev)
+            jpose = torch.from_numpy(jj_exp_h - t0).to(dev)
             m = (disps_sens[kx] > 0).to(f32).view(-1, HW)
             eta_v = eta.reshape(-1, HW).to(f32)
             acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
@@ -162,7 +162,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                 Eall = torch.cat([Ei, Eij], 0).contiguous()                                             # :1401
                 nE = Eall.shape[0]
                 S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
-                if trip:
+                if have_pairs:
                     _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
                     asm_S(S.view(-1, 36), A, -1.0, st)
                 sv = torch.empty((nE, 6), dtype=f32, device=dev)

@@ -90,4 +90,24 @@ with torch.no_grad():
         lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, iib, jjb, 2, N, 2, 1e-4, 0.1, False)
 
     res["ba: 12 keyframes 48x64, %d edges, 2 iterations (ms, wall incl. host bookkeeping)" % len(ii_l)] = wall(run_ba, iters=10, warm=2)
+    # backend-sized BA: 200 keyframes of 60x80, edges within 5 frames (1970 edges), window [1, 200), 2 iterations
+    N, h, w = 200, 60, 80
+    ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= 5]
+    jj_l = [j for i in range(N) for j in range(N) if i != j and abs(i - j) <= 5]
+    iib, jjb = torch.tensor(ii_l, device=dev), torch.tensor(jj_l, device=dev)
+    poses = torch.zeros(N, 7, device=dev)
+    poses[:, 6] = 1
+    poses[:, 0] = torch.arange(N, device=dev) * 0.05
+    disps = 0.3 + 0.7 * torch.rand(N, h, w, device=dev)
+    intr = torch.tensor([60.0, 60.0, 40.0, 30.0], device=dev)
+    ys2, xs2 = torch.meshgrid(torch.arange(h, device=dev).float(), torch.arange(w, device=dev).float(), indexing="ij")
+    tgt = torch.stack([xs2, ys2])[None].repeat(len(ii_l), 1, 1, 1) + torch.randn(len(ii_l), 2, h, w, device=dev)
+    wgt = torch.rand(len(ii_l), 2, h, w, device=dev)
+    eta = torch.full((N, h, w), 1e-3, device=dev)
+    sens = torch.zeros_like(disps)
+
+    def run_ba_backend():
+        lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, iib, jjb, 1, N, 2, 1e-4, 0.1, False)
+
+    res["ba: 200 keyframes 60x80, %d edges, 2 iterations (ms, wall incl. host bookkeeping; 1194x1194 system, library Cholesky)" % len(ii_l)] = wall(run_ba_backend, iters=3, warm=1)
 print(json.dumps(res, indent=1))
