@@ -207,3 +207,44 @@ def test_hip_ba_is_bit_reproducible(lgu):
         dx, dz = lgu.ba.ba(pd, dd, idv, sd, td, wd_, ed, iid, jjd, 1, len(p), 3, 1e-4, 0.1, False)
         outs.append((pd.clone(), dd.clone(), dx.clone(), dz.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 3, 21])
+def test_device_cholesky_solve_against_numpy(lgu, P):
+    """lgu_ba_solve_f64: (A + diag(ep + lm diag A)) x = b in one workgroup with the matrix in LDS (6P <= 126, the
+    frontend window), against numpy.linalg in double; a matrix that is not positive definite gives x = 0, as the
+    reference's Eigen path does; larger systems are reported unsupported (the glue then uses a library factorisation)."""
+    import ctypes
+    rng = np.random.default_rng(100 + P)
+    n = 6 * P
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    lm, ep = 1e-4, 0.1
+    L = A.copy()
+    L[np.diag_indices(n)] += ep + lm * np.diag(A)
+    want = np.linalg.solve(L, b)
+    lib = lgu._lib.load()
+
+    def solve(Am, Pn=P):
+        Ad = torch.from_numpy(np.ascontiguousarray(Am)).cuda()
+        bd = torch.from_numpy(b).cuda()
+        x = torch.full((Pn, 6), 7.0, dtype=torch.float32, device="cuda")
+        rc = lib.lgu_ba_solve_f64(ctypes.c_void_p(Ad.data_ptr()), ctypes.c_void_p(bd.data_ptr()), ctypes.c_void_p(x.data_ptr()), Pn, lm,
+                                  ep, None)
+        torch.cuda.synchronize()
+        assert torch.equal(Ad.cpu(), torch.from_numpy(np.ascontiguousarray(Am)))   # A is not modified
+        return rc, x.cpu().numpy().reshape(-1)
+
+    rc, got = solve(A)
+    assert rc == 0 and np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())      # float32 output of a double solve
+    Abad = A.copy()
+    Abad[n // 2, n // 2] = -5.0 * np.abs(A).max()
+    rc, got = solve(Abad)
+    assert rc == 0 and not got.any()
+    if P == 21:
+        big = np.eye(6 * 22)
+        rc = lib.lgu_ba_solve_f64(ctypes.c_void_p(torch.from_numpy(big).cuda().data_ptr()), ctypes.c_void_p(torch.zeros(132, dtype=torch.float64, device="cuda").data_ptr()),
+                                  ctypes.c_void_p(torch.zeros(22, 6, device="cuda").data_ptr()), 22, lm, ep, None)
+        assert rc == lgu._lib.LGU_E_UNSUPPORTED
