@@ -182,8 +182,13 @@ __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
 // ---- segment sums: out[j][:] = sum of inp[idxs[i]][:] for i in [ptrs[j], ptrs[j+1])  (:854-874) ----
 __global__ __launch_bounds__(BA_THREADS) void ba_accum_kernel(const float* __restrict__ inp, const long long* __restrict__ ptrs,
                                                               const long long* __restrict__ idxs, float* __restrict__ out, int D) {
+  // grid = (output rows, 1024-element chunks of a row): enough workgroups to fill the chip when there are few frames
   const int start = (int)ptrs[blockIdx.x], end = (int)ptrs[blockIdx.x + 1];
-  for (int k = threadIdx.x; k < D; k += BA_THREADS) {
+  const int k0 = blockIdx.y * (BA_THREADS * 4) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int k = k0 + u * BA_THREADS;
+    if (k >= D) break;
     float x = 0.f;
     for (int i = start; i < end; i++) x += inp[(size_t)idxs[i] * D + k];
     out[(size_t)blockIdx.x * D + k] = x;
@@ -438,8 +443,8 @@ int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* i
   using namespace lgu;
   if (!inp || !ptrs || !out || nout < 0 || D < 1) return LGU_E_BADARG;
   if (nout == 0) return LGU_OK;
-  hipLaunchKernelGGL(ba_accum_kernel, dim3(nout), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs,
-                     out, D);
+  hipLaunchKernelGGL(ba_accum_kernel, dim3(nout, (D + BA_THREADS * 4 - 1) / (BA_THREADS * 4)), dim3(BA_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs, out, D);
   return launch_status();
 }
 
