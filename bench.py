@@ -170,10 +170,32 @@ def dry_run_cpu(args, rank, world):
                "roofline": None, "cpu_baseline": None}
         if exchange:
             res["exchange"] = exchange
-        print(json.dumps(res, ensure_ascii=False))
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Everything that libraries print to stdout while the benchmark runs (RCCL prints a host / library banner on
+    communicator creation) goes to stderr; the ONE JSON line is written to the real stdout by emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj, ensure_ascii=False) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def lowmem_main(args, ops, dev, rank, world, use_dist):
@@ -255,7 +277,7 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
                             "note": "the contraction is 2.2 % of the dense f16 MFMA peak by design: the kernel is bound by L2 -> CU "
                                     "reads of the swept windows (DESIGN.md §3.4), the matrix cores are idle most of the time"},
                "cpu_baseline": cpu}
-        print(json.dumps(res, ensure_ascii=False))
+        emit(res)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
@@ -292,6 +314,7 @@ def main():
         return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    quiet_stdout()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # launched by torch.distributed.run
@@ -410,7 +433,7 @@ def main():
         }
         if exchange:
             res["exchange"] = exchange
-        print(json.dumps(res, ensure_ascii=False))
+        emit(res)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
