@@ -223,6 +223,11 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  *   targets (E,2,ht,wd) with weights (E,2,ht,wd), pose / depth Jacobians; Hs (4,E,6,6) = Hii,Hij,Hji,Hjj, vs (2,E,6),
  *   Eii, Eij (E,6,ht*wd), Cii, wi (E,ht*wd), all fully written.  poses (N,7) = t, q(xyzw); disps (N,ht,wd); intrinsics (4).
  * lgu_ba_accum_f32        accum_kernel (:854-874): out[j] = sum of inp rows idxs[ptrs[j] .. ptrs[j+1]), rows of D floats.
+ * lgu_ba_depth_system_f32 the depth block of the normal equations in one pass (ba_cuda :1394-1398): for depth frame kx[j],
+ *                         C = sum_{edges of the frame} Cii + m*0.05 + (1-m)*eta, w = sum wi - m*0.05*(disps - disps_sens),
+ *                         m = (disps_sens > 0); writes Q = 1/C and w, both (K,ht*wd).  Segment tables as lgu_ba_accum_f32;
+ *                         eta (eta_rows, ht*wd) with eta_rows in {1, K}.
+ * lgu_ba_depth_update_f32 dz = Q (w - sum_{E entries of the frame} dw) (:1415) and disps[kx[j]] += dz (:933-946) in one pass.
  * lgu_ba_scatter_sum_f64  assembly of the reduced camera system (SparseBlock::update_lhs / update_rhs :1137-1179, on the CPU
  *                         in the reference): out[dst[j]] += sign * sum of inp rows idxs[ptrs[j] .. ptrs[j+1]) in double, rows of
  *                         D floats; one thread per output component, fixed summation order (bit-reproducible).
@@ -241,6 +246,11 @@ int lgu_ba_build_f32(const float* targets, const float* weights, const float* po
                      float* Hs, float* vs, float* Eii, float* Eij, float* Cii, float* wi,
                      int E, int ht, int wd, void* stream);
 int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* idxs, float* out, int nout, int D, void* stream);
+int lgu_ba_depth_system_f32(const float* Cii, const float* wi, const long long* ptrs, const long long* idxs, const long long* kx,
+                            const float* disps, const float* disps_sens, const float* eta, int eta_rows, float* Q, float* w,
+                            int K, int HW, void* stream);
+int lgu_ba_depth_update_f32(const float* Q, const float* w, const float* dw, const long long* ptrs, const long long* idxs,
+                            const long long* kx, float* dz, float* disps, int K, int HW, void* stream);
 int lgu_ba_scatter_sum_f64(const float* inp, const long long* ptrs, const long long* idxs, const long long* dst, double* out,
                            int m, int D, double sign, void* stream);
 int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* S, int nblocks, int D, void* stream);

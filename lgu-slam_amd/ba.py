@@ -131,8 +131,12 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             asm_S = _ScatterSum(lib, (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0) if have_pairs else np.zeros(0, np.int64), dev)
             asm_sv = _ScatterSum(lib, jj_exp_h - t0, dev)
             jpose = torch.from_numpy(jj_exp_h - t0).to(dev)
-            m = (disps_sens[kx] > 0).to(f32).view(-1, HW)
-            eta_v = eta.reshape(-1, HW).to(f32)
+            eta_v = eta.reshape(-1, HW).to(f32).contiguous()
+            K = kx.shape[0]
+            if eta_v.shape[0] not in (1, K):
+                raise RuntimeError("ba: eta must have one row per depth frame (%d) or one row, got %d" % (K, eta_v.shape[0]))
+            Q = torch.empty((K, HW), dtype=f32, device=dev)
+            w = torch.empty((K, HW), dtype=f32, device=dev)
             acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
             acc_ii_ts = _Accum(lib, ii_h, ts_h, dev)
             acc_exp_kx = _Accum(lib, ii_exp_h, kx_h, dev)
@@ -154,10 +158,9 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             b = torch.zeros((P, 6), dtype=f64, device=dev)
             asm_v(vs.view(-1, 6), b, 1.0, st)
             if not motion_only:
-                C = acc_ii_kx(Cii, st) + m * _ALPHA + (1 - m) * eta_v                       # :1396
-                w = acc_ii_kx(wi, st) - m * _ALPHA * (disps[kx] - disps_sens[kx]).view(-1, HW)   # :1397
-                Q = (1.0 / C).contiguous()
-                w = w.contiguous()
+                _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
+                                                       _ptr(disps_sens), _ptr(eta_v), eta_v.shape[0], _ptr(Q), _ptr(w), K, HW, st),
+                           "ba depth system")                                                          # :1394-1398
                 Ei = acc_ii_ts(Eii.view(E, 6 * HW), st).view(P, 6, HW)                     # :1400
                 Eall = torch.cat([Ei, Eij], 0).contiguous()                                             # :1401
                 nE = Eall.shape[0]
@@ -178,8 +181,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
             if not motion_only:
                 dw = torch.empty((nE, HW), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose.contiguous()), _ptr(dw), nE, HW, P, st), "ba EvT")
-                dz = (Q * (w - acc_exp_kx(dw, st))).contiguous()                       # :1415
+                dz = torch.empty((K, HW), dtype=f32, device=dev)
+                _lib.check(lib.lgu_ba_depth_update_f32(_ptr(Q), _ptr(w), _ptr(dw), _ptr(acc_exp_kx.ptrs), _ptr(acc_exp_kx.cols), _ptr(kx),
+                                                       _ptr(dz), _ptr(disps), K, HW, st), "ba depth update")  # :1415, :933-946
             _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
-            if not motion_only:
-                _lib.check(lib.lgu_ba_disp_retr_f32(_ptr(disps), _ptr(dz), _ptr(kx), kx.shape[0], HW, st), "ba disp retraction")
     return [dx, dz]

@@ -195,6 +195,58 @@ __global__ __launch_bounds__(BA_THREADS) void ba_accum_kernel(const float* __res
   }
 }
 
+// ---- depth system in one pass (ba_cuda :1394-1398): for depth frame j and pixel k
+//   C = sum_{edges with ii == kx[j]} Cii + m*alpha + (1 - m)*eta,   w = sum wi - m*alpha*(disp - disp_sens),   Q = 1/C
+// with m = (disp_sens > 0).  Replaces two segment sums and eight elementwise tensor passes.
+__global__ __launch_bounds__(BA_THREADS) void ba_depth_system_kernel(const float* __restrict__ Cii, const float* __restrict__ wi,
+                                                                     const long long* __restrict__ ptrs, const long long* __restrict__ idxs,
+                                                                     const long long* __restrict__ kx, const float* __restrict__ disps,
+                                                                     const float* __restrict__ sens, const float* __restrict__ eta,
+                                                                     int eta_rows, float alpha, float* __restrict__ Q,
+                                                                     float* __restrict__ w, int D) {
+  const int j = blockIdx.x;
+  const int start = (int)ptrs[j], end = (int)ptrs[j + 1];
+  const size_t f = (size_t)kx[j];
+  const float* const er = eta + (size_t)(eta_rows == 1 ? 0 : j) * D;
+  const int k0 = blockIdx.y * (BA_THREADS * 4) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int k = k0 + u * BA_THREADS;
+    if (k >= D) break;
+    float c = 0.f, b = 0.f;
+    for (int i = start; i < end; i++) {
+      c += Cii[(size_t)idxs[i] * D + k];
+      b += wi[(size_t)idxs[i] * D + k];
+    }
+    const float ds = sens[f * D + k], dd = disps[f * D + k];
+    const float m = ds > 0.f ? 1.0f : 0.0f;
+    const float C = c + m * alpha + (1.0f - m) * er[k];
+    w[(size_t)j * D + k] = b - m * alpha * (dd - ds);
+    Q[(size_t)j * D + k] = 1.0f / C;
+  }
+}
+
+// ---- depth update in one pass (:1415, :933-946): dz = Q (w - sum_{entries of frame j} dw); disps[kx[j]] += dz ----
+__global__ __launch_bounds__(BA_THREADS) void ba_depth_update_kernel(const float* __restrict__ Q, const float* __restrict__ w,
+                                                                     const float* __restrict__ dw, const long long* __restrict__ ptrs,
+                                                                     const long long* __restrict__ idxs, const long long* __restrict__ kx,
+                                                                     float* __restrict__ dz, float* disps, int D) {
+  const int j = blockIdx.x;
+  const int start = (int)ptrs[j], end = (int)ptrs[j + 1];
+  const size_t f = (size_t)kx[j];
+  const int k0 = blockIdx.y * (BA_THREADS * 4) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int k = k0 + u * BA_THREADS;
+    if (k >= D) break;
+    float a = 0.f;
+    for (int i = start; i < end; i++) a += dw[(size_t)idxs[i] * D + k];
+    const float z = Q[(size_t)j * D + k] * (w[(size_t)j * D + k] - a);
+    dz[(size_t)j * D + k] = z;
+    disps[f * D + k] += z;
+  }
+}
+
 // ---- deterministic assembly: out[dst[j]][:] += sign * sum of inp[idxs[i]][:], i in [ptrs[j], ptrs[j+1]), in double.
 // One thread per (destination, component), rows summed in table order: the replicated BA of a sharded run must
 // produce the same bits on every rank, which atomics-based index_add would not guarantee.
@@ -445,6 +497,28 @@ int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* i
   if (nout == 0) return LGU_OK;
   hipLaunchKernelGGL(ba_accum_kernel, dim3(nout, (D + BA_THREADS * 4 - 1) / (BA_THREADS * 4)), dim3(BA_THREADS), 0,
                      reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs, out, D);
+  return launch_status();
+}
+
+int lgu_ba_depth_system_f32(const float* Cii, const float* wi, const long long* ptrs, const long long* idxs, const long long* kx,
+                            const float* disps, const float* disps_sens, const float* eta, int eta_rows, float* Q, float* w, int K,
+                            int HW, void* stream) {
+  using namespace lgu;
+  if (!Cii || !wi || !ptrs || !idxs || !kx || !disps || !disps_sens || !eta || !Q || !w || K < 0 || HW < 1) return LGU_E_BADARG;
+  if (eta_rows != 1 && eta_rows != K) return LGU_E_BADARG;
+  if (K == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_depth_system_kernel, dim3(K, (HW + BA_THREADS * 4 - 1) / (BA_THREADS * 4)), dim3(BA_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), Cii, wi, ptrs, idxs, kx, disps, disps_sens, eta, eta_rows, 0.05f, Q, w, HW);
+  return launch_status();
+}
+
+int lgu_ba_depth_update_f32(const float* Q, const float* w, const float* dw, const long long* ptrs, const long long* idxs,
+                            const long long* kx, float* dz, float* disps, int K, int HW, void* stream) {
+  using namespace lgu;
+  if (!Q || !w || !dw || !ptrs || !idxs || !kx || !dz || !disps || K < 0 || HW < 1) return LGU_E_BADARG;
+  if (K == 0) return LGU_OK;
+  hipLaunchKernelGGL(ba_depth_update_kernel, dim3(K, (HW + BA_THREADS * 4 - 1) / (BA_THREADS * 4)), dim3(BA_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), Q, w, dw, ptrs, idxs, kx, dz, disps, HW);
   return launch_status();
 }
 
