@@ -43,8 +43,9 @@ class _Accum:
         self.ptrs = torch.from_numpy(np.ascontiguousarray(ptrs, dtype=np.int64)).to(dev)
         self.cols = torch.from_numpy(np.ascontiguousarray(cols if len(cols) else [0], dtype=np.int64)).to(dev)
 
-    def __call__(self, data, st):
-        out = torch.empty((self.n, data.shape[1]), dtype=torch.float32, device=data.device)
+    def __call__(self, data, st, out=None):
+        if out is None:
+            out = torch.empty((self.n, data.shape[1]), dtype=torch.float32, device=data.device)
         if self.n:
             _lib.check(self.lib.lgu_ba_accum_f32(_ptr(data), _ptr(self.ptrs), _ptr(self.cols), _ptr(out), self.n, data.shape[1], st),
                        "ba accum")
@@ -144,7 +145,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
         vs = torch.empty((2, E, 6), dtype=f32, device=dev)
         Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
-        Eij = torch.empty((E, 6, HW), dtype=f32, device=dev)
+        Eall = torch.empty((P + E, 6, HW), dtype=f32, device=dev)   # E = cat(Ei, Eij) (:1401) without the copy:
+        Eij = Eall[P:]                                               # the build kernel writes Eij in place, Ei is summed into the head
         Cii = torch.empty((E, HW), dtype=f32, device=dev)
         wi = torch.empty((E, HW), dtype=f32, device=dev)
         dx = torch.zeros((P, 6), dtype=f32, device=dev)
@@ -161,9 +163,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                 _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
                                                        _ptr(disps_sens), _ptr(eta_v), eta_v.shape[0], _ptr(Q), _ptr(w), K, HW, st),
                            "ba depth system")                                                          # :1394-1398
-                Ei = acc_ii_ts(Eii.view(E, 6 * HW), st).view(P, 6, HW)                     # :1400
-                Eall = torch.cat([Ei, Eij], 0).contiguous()                                             # :1401
-                nE = Eall.shape[0]
+                acc_ii_ts(Eii.view(E, 6 * HW), st, out=Eall[:P].view(P, 6 * HW))             # :1400-1401
+                nE = P + E
                 S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
                 if have_pairs:
                     _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
