@@ -222,6 +222,8 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  * lgu_ba_build_f32        projective_transform_kernel (:176-425): per edge e = (ii[e] -> jj[e]): reprojection residual of
  *   targets (E,2,ht,wd) with weights (E,2,ht,wd), pose / depth Jacobians; Hs (4,E,6,6) = Hii,Hij,Hji,Hjj, vs (2,E,6),
  *   Eii, Eij (E,6,ht*wd), Cii, wi (E,ht*wd), all fully written.  poses (N,7) = t, q(xyzw); disps (N,ht,wd); intrinsics (4).
+ *   An edge's pixels are split over lgu_ba_build_slices(E) workgroups (so that tens of edges still fill 256 CUs);
+ *   `scratch` (device, E * slices * 90 floats) holds their partial sums, which a second kernel adds in slice order.
  * lgu_ba_accum_f32        accum_kernel (:854-874): out[j] = sum of inp rows idxs[ptrs[j] .. ptrs[j+1]), rows of D floats.
  * lgu_ba_depth_system_f32 the depth block of the normal equations in one pass (ba_cuda :1394-1398): for depth frame kx[j],
  *                         C = sum_{edges of the frame} Cii + m*0.05 + (1-m)*eta, w = sum wi - m*0.05*(disps - disps_sens),
@@ -243,8 +245,9 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  * lgu_ba_disp_retr_f32    disp_retr_kernel (:933-946): disps[inds[b]] += dz[b]. */
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
                      const float* intrinsics, const long long* ii, const long long* jj,
-                     float* Hs, float* vs, float* Eii, float* Eij, float* Cii, float* wi,
+                     float* Hs, float* vs, float* Eii, float* Eij, float* Cii, float* wi, float* scratch,
                      int E, int ht, int wd, void* stream);
+int lgu_ba_build_slices(int E);
 int lgu_ba_accum_f32(const float* inp, const long long* ptrs, const long long* idxs, float* out, int nout, int D, void* stream);
 int lgu_ba_depth_system_f32(const float* Cii, const float* wi, const long long* ptrs, const long long* idxs, const long long* kx,
                             const float* disps, const float* disps_sens, const float* eta, int eta_rows, float* Q, float* w,

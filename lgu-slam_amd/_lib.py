@@ -36,7 +36,8 @@ SIGNATURES = {
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
     "lgu_lowmem_pyramid_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
-    "lgu_ba_build_f32": [_vp] * 13 + [_int] * 3 + [_vp],
+    "lgu_ba_build_f32": [_vp] * 14 + [_int] * 3 + [_vp],
+    "lgu_ba_build_slices": [_int],
     "lgu_ba_accum_f32": [_vp] * 4 + [_int] * 2 + [_vp],
     "lgu_ba_depth_system_f32": [_vp] * 8 + [_int] + [_vp] * 2 + [_int] * 2 + [_vp],
     "lgu_ba_depth_update_f32": [_vp] * 8 + [_int] * 2 + [_vp],

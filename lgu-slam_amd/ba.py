@@ -147,13 +147,15 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
         Eall = torch.empty((P + E, 6, HW), dtype=f32, device=dev)   # E = cat(Ei, Eij) (:1401) without the copy:
         Eij = Eall[P:]                                               # the build kernel writes Eij in place, Ei is summed into the head
+        scratch = torch.empty((max(E, 1) * lib.lgu_ba_build_slices(E) * 90,), dtype=f32, device=dev)
         Cii = torch.empty((E, HW), dtype=f32, device=dev)
         wi = torch.empty((E, HW), dtype=f32, device=dev)
         dx = torch.zeros((P, 6), dtype=f32, device=dev)
         dz = None
         for _ in range(iterations):
             _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
-                                            _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), E, ht, wd, st),
+                                            _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
+                                            st),
                        "ba build")
             A = torch.zeros((P * P, 36), dtype=f64, device=dev)
             asm_H(Hs.view(-1, 36), A, 1.0, st)

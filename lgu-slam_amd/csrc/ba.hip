@@ -66,10 +66,15 @@ __device__ __forceinline__ float block_sum(float v, float* red /* [4] */) {
 __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ poses,
     const float* __restrict__ disps, const float* __restrict__ intrinsics, const long long* __restrict__ ii,
-    const long long* __restrict__ jj, float* __restrict__ Hs, float* __restrict__ vs, float* __restrict__ Eii,
-    float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz, int E, int HW, int wd) {
+    const long long* __restrict__ jj, float* __restrict__ part, float* __restrict__ Eii,
+    float* __restrict__ Eij, float* __restrict__ Cii, float* __restrict__ bz, int E, int HW, int wd, int slices) {
+  // grid = (edges, slices): an edge's pixels are split over `slices` workgroups so that a frontend-sized graph
+  // (tens of edges) still fills the 256 CUs; each writes its 90 partial sums (78 Hessian + 6 + 6 gradient entries)
+  // to part[e][slice][:], ba_build_finalize_kernel adds them in slice order (deterministic) into Hs / vs.
   __shared__ float red[4];
   const int e = blockIdx.x;
+  const int chunk = (HW + slices - 1) / slices;
+  const int kbeg = blockIdx.y * chunk, kend = kbeg + chunk < HW ? kbeg + chunk : HW;
   const int ix = (int)ii[e], jx = (int)jj[e];
   const float fx = intrinsics[0], fy = intrinsics[1], cx = intrinsics[2], cy = intrinsics[3];
   float tij[3], qij[4];
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
 #pragma unroll
   for (int n = 0; n < 6; n++) vi[n] = vj[n] = 0.f;
   const size_t eo = (size_t)e * HW;
-  for (int k = threadIdx.x; k < HW; k += BA_THREADS) {
+  for (int k = kbeg + threadIdx.x; k < kend; k += BA_THREADS) {
     const int i = k / wd, j = k - i * wd;
     float Xi[3] = {((float)j - cx) / fx, ((float)i - cy) / fy, 1.0f}, Xj[3];
     const float h = disps[(size_t)ix * HW + k];
@@ -152,31 +157,42 @@ __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
     Cii[eo + k] = cii;
     bz[eo + k] = b;
   }
-  // block reductions (:369-424)
+  // block reductions (:369-424) into this slice's partial record: [0,78) hij, [78,84) vi, [84,90) vj
+  float* const rec = part + ((size_t)e * slices + blockIdx.y) * 90;
+#pragma unroll
+  for (int l = 0; l < 78; l++) {
+    const float sum = block_sum(hij[l], red);
+    if (threadIdx.x == 0) rec[l] = sum;
+  }
 #pragma unroll
   for (int n = 0; n < 6; n++) {
     const float a = block_sum(vi[n], red), c = block_sum(vj[n], red);
-    if (threadIdx.x == 0) {
-      vs[((size_t)0 * E + e) * 6 + n] = a;
-      vs[((size_t)1 * E + e) * 6 + n] = c;
-    }
+    if (threadIdx.x == 0) { rec[78 + n] = a; rec[84 + n] = c; }
   }
-  {
-    int l = 0;
-#pragma unroll
-    for (int n = 0; n < 12; n++)
-#pragma unroll
-      for (int m = 0; m <= n; m++) {
-        const float s = block_sum(hij[l++], red);
-        if (threadIdx.x == 0) {
-          float* const H0 = Hs + ((size_t)0 * E + e) * 36, * const H1 = Hs + ((size_t)1 * E + e) * 36;
-          float* const H2 = Hs + ((size_t)2 * E + e) * 36, * const H3 = Hs + ((size_t)3 * E + e) * 36;
-          if (n < 6 && m < 6) { H0[n * 6 + m] = s; H0[m * 6 + n] = s; }
-          else if (n >= 6 && m < 6) { H1[m * 6 + (n - 6)] = s; H2[(n - 6) * 6 + m] = s; }
-          else { H3[(n - 6) * 6 + (m - 6)] = s; H3[(m - 6) * 6 + (n - 6)] = s; }
-        }
-      }
+}
+
+// Adds the slice records of every edge in slice order and lays the blocks out as the reference does (:400-421):
+// Hs (4,E,6,6) = Hii, Hij, Hji, Hjj; vs (2,E,6).  One thread per (edge, entry).
+__global__ __launch_bounds__(BA_THREADS) void ba_build_finalize_kernel(const float* __restrict__ part, float* __restrict__ Hs,
+                                                                       float* __restrict__ vs, int E, int slices) {
+  const int t = blockIdx.x * BA_THREADS + threadIdx.x;
+  if (t >= E * 90) return;
+  const int e = t / 90, l = t - e * 90;
+  float sum = 0.f;
+  for (int sl = 0; sl < slices; sl++) sum += part[((size_t)e * slices + sl) * 90 + l];
+  if (l >= 78) {
+    const int n = l - 78;
+    vs[((size_t)(n / 6) * E + e) * 6 + n % 6] = sum;
+    return;
   }
+  int n = 0;
+  while ((n + 1) * (n + 2) / 2 <= l) n++;  // packed lower-triangular index l -> (n, m), m <= n
+  const int m = l - n * (n + 1) / 2;
+  float* const H0 = Hs + ((size_t)0 * E + e) * 36, * const H1 = Hs + ((size_t)1 * E + e) * 36;
+  float* const H2 = Hs + ((size_t)2 * E + e) * 36, * const H3 = Hs + ((size_t)3 * E + e) * 36;
+  if (n < 6) { H0[n * 6 + m] = sum; H0[m * 6 + n] = sum; }
+  else if (m < 6) { H1[m * 6 + (n - 6)] = sum; H2[(n - 6) * 6 + m] = sum; }
+  else { H3[(n - 6) * 6 + (m - 6)] = sum; H3[(m - 6) * 6 + (n - 6)] = sum; }
 }
 
 // ---- segment sums: out[j][:] = sum of inp[idxs[i]][:] for i in [ptrs[j], ptrs[j+1])  (:854-874) ----
@@ -463,6 +479,14 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
 
 extern "C" {
 
+/* Pixel slices per edge of lgu_ba_build_f32 (the caller sizes `scratch` = E * slices * 90 floats with it). */
+int lgu_ba_build_slices(int E) {
+  if (E <= 0) return 1;
+  const int s = (512 + E - 1) / E;
+  return s < 1 ? 1 : (s > 8 ? 8 : s);
+}
+
+
 int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double lm, double ep, void* stream) {
   using namespace lgu;
   if (!A || !b || !x || P < 1) return LGU_E_BADARG;
@@ -480,14 +504,18 @@ int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double l
 
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
                      const float* intrinsics, const long long* ii, const long long* jj, float* Hs, float* vs, float* Eii,
-                     float* Eij, float* Cii, float* wi, int E, int ht, int wd, void* stream) {
+                     float* Eij, float* Cii, float* wi, float* scratch, int E, int ht, int wd, void* stream) {
   using namespace lgu;
-  if (!targets || !weights || !poses || !disps || !intrinsics || !ii || !jj || !Hs || !vs || !Eii || !Eij || !Cii || !wi)
+  if (!targets || !weights || !poses || !disps || !intrinsics || !ii || !jj || !Hs || !vs || !Eii || !Eij || !Cii || !wi || !scratch)
     return LGU_E_BADARG;
   if (E < 0 || ht < 1 || wd < 1) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
-  hipLaunchKernelGGL(ba_build_kernel, dim3(E), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), targets, weights,
-                     poses, disps, intrinsics, ii, jj, Hs, vs, Eii, Eij, Cii, wi, E, ht * wd, wd);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int slices = lgu_ba_build_slices(E);
+  hipLaunchKernelGGL(ba_build_kernel, dim3(E, slices), dim3(BA_THREADS), 0, st, targets, weights, poses, disps, intrinsics, ii, jj,
+                     scratch, Eii, Eij, Cii, wi, E, ht * wd, wd, slices);
+  hipLaunchKernelGGL(ba_build_finalize_kernel, dim3((E * 90 + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, st, scratch, Hs, vs, E,
+                     slices);
   return launch_status();
 }
 
