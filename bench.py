@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--layout", choices=["tiled", "rowmajor"], default="tiled",
                     help="storage of the pyramid the sampler reads: 'tiled' = the 4x8-tile slice layout CorrBlock keeps "
                          "its pyramid in (production), 'rowmajor' = the reference operator's layout (drop-in operator path)")
+    ap.add_argument("--out-format", choices=["planar", "nhwc", "nhwc_f16"], default="planar",
+                    help="output tensor: 'planar' = the reference's contiguous (E,196,H,W) fp32; 'nhwc' / 'nhwc_f16' = the "
+                         "same values channel-last in fp32 / half, the form the consumer 1x1 convolution takes (tiled layout only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -342,7 +345,10 @@ def main():
     if tiled:  # what CorrBlock.__init__ (ops.volume_pyramid(tiled=True)) leaves in HBM; conversion is setup, not timed
         rowmajor_vols = vols
         vols = [ops.volume_retile(v) for v in rowmajor_vols]
-    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe, tiled=tiled, level_hw=level_hw)
+    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe, tiled=tiled, level_hw=level_hw,
+                                  out_format=args.out_format)
+    if args.out_format != "planar":
+        out = ops._pyr_out(args.out_format, E, L * (2 * R + 1) ** 2, H1, W1, dev, None)
 
     def step():
         # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful
@@ -396,18 +402,22 @@ def main():
 
     if rank == 0:
         A, U = algorithmic_bytes_per_unit(rowmajor_vols if tiled else vols, coords, offs, R)
+        if args.out_format == "nhwc_f16":  # the output row is 2-byte elements
+            A -= L * (2 * R + 1) ** 2 * 2
         kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
                  5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
                  3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
                  2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
         kname = kname.replace("LAYOUT", "true" if tiled else "false")
+        if args.out_format != "planar":
+            kname = kname[:-1] + (",1>" if args.out_format == "nhwc" else ",2>")
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
         # because counters cannot be collected from inside the timed process; see profiles/.
         traffic, traffic_src = None, None
         tname = "traffic_r01_tiled.json" if tiled else "traffic_r01.json"
         tfile = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tfile) and E == 20 and not args.probe:
+        if os.path.exists(tfile) and E == 20 and not args.probe and args.out_format == "planar":
             t = json.load(open(tfile))
             if t.get("kernel") == kname:
                 traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/" + tname
@@ -423,7 +433,8 @@ def main():
                        "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
                        "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid",
                        "pyramid_layout": "4x8-tiled slices (CorrBlock's own storage; results bit-identical)" if tiled
-                                         else "row-major slices (reference operator layout)"},
+                                         else "row-major slices (reference operator layout)",
+                       "out_format": args.out_format},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": A * units,

@@ -108,6 +108,14 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
  *   operator's (E,2,H1,W1) planes: saves the permute().contiguous() pass of corr.py:91 in front of every lookup.
  *   Served by the fast kernels (radius 1..3, 16-byte aligned operands); otherwise LGU_E_UNSUPPORTED. */
 #define LGU_PYR_COORDS_LAST 4
+/* LGU_PYR_OUT_NHWC: out is channel-last, (E, H1, W1, L*rd*rd) — the memory format the consumer of the lookup, the 1x1
+ *   convolution of UpdateModule.corr_encoder (droid_net.py:76-80), prefers — instead of (E, L*rd*rd, H1, W1); same
+ *   values.  LGU_PYR_OUT_F16 (with LGU_PYR_OUT_NHWC only, else LGU_E_BADARG): out holds IEEE half, each value the
+ *   round-to-nearest-even of the fp32 result, i.e. exactly the cast autocast applies in front of that convolution
+ *   (factor_graph.py wraps the update operator in autocast); `out` then points at E*H1*W1*L*rd*rd 2-byte elements.
+ *   Served by the production kernel (LGU_PYR_TILED, radius 3); otherwise LGU_E_UNSUPPORTED. */
+#define LGU_PYR_OUT_NHWC 8
+#define LGU_PYR_OUT_F16 16
 int lgu_defcorr_pyramid_fwd_f32(const float* const* volumes, const float* coords,
                                 float* const* offsets, float* out,
                                 int L, int E, int H1, int W1, const int* H2, const int* W2,

@@ -9,8 +9,9 @@ module `lgu_slam_amd.py` at the repository root.
 import os
 import sys
 
-from . import _build, _lib, ba, ops, sharded  # noqa: F401
+from . import _build, _lib, ba, encoder, ops, sharded  # noqa: F401
 from .corr import AltCorrBlock, CorrBlock, CorrSampler, DefCorrSampler, per_Corr_Normalization  # noqa: F401
+from .encoder import CorrEncoder  # noqa: F401
 from .gaussian_mask import GaussianMask, GaussianMaskCuda  # noqa: F401
 
 __version__ = "0.2.0"

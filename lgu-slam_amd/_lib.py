@@ -62,7 +62,7 @@ class UnsupportedShape(RuntimeError):
     """The kernels do not serve this shape / argument pattern (LGU_E_UNSUPPORTED)."""
 
 
-LGU_E_UNSUPPORTED = 100002
+LGU_E_BADARG, LGU_E_UNSUPPORTED = 100001, 100002
 
 
 def so_path():

@@ -416,7 +416,11 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // the first result is used.  Far fewer instructions per pixel than the LDS-DMA kernel; the
 // price is L1/TA work per corner instead of per line.
 // GP = pixels per wave, TPX = pixels (along x) per workgroup: TPX / GP waves per workgroup
-template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED>
+// OUTM = output form: 0 = planar fp32 (E, L*NT, H1, W1), the reference's tensor, written through the LDS transpose
+// tile; 1 / 2 = channel-last (E, H1, W1, L*NT) in fp32 / half (LGU_PYR_OUT_NHWC [| LGU_PYR_OUT_F16]) — the form the
+// consumer 1x1 convolution of the update operator prefers (droid_net.py:76-80 under autocast).  With lanes = taps a
+// wave's store is already one contiguous run of the pixel's channels, so these forms need no LDS and no barrier.
+template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED, int OUTM = 0>
 __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   constexpr int LAT = 2 * R + 2;
@@ -598,7 +602,16 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     }
   }
 
-  // ---- phase B: blend, park in the transpose tile ----
+  // ---- phase B: blend, park in the transpose tile (or store the channel-last row directly) ----
+  auto put = [&](int l, int ch, int pc, float val) __attribute__((always_inline)) {
+    if constexpr (OUTM == 0) {
+      outst[(l * NT + ch) * (TPX + 1) + pc] = val;
+    } else {
+      const size_t o = (row_pix + xbase + pc) * (size_t)p.Ctot + p.cbase + l * NT + ch;
+      if constexpr (OUTM == 1) p.out[o] = val;
+      else reinterpret_cast<_Float16*>(p.out)[o] = (_Float16)val;  // v_cvt_f16_f32, round-to-nearest-even = Tensor.half()
+    }
+  };
 #pragma unroll
   for (int k = 0; k < GP; k++) {
     const int px = xbase + w * GP + k;
@@ -625,7 +638,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
         float val = 0.0f;
         if (in_bounds(y1, x1, H2, W2)) val = bilerp(q11, q21, q12, q22, dx, dy);
         if (ltap && pxl < p.W1 && (PIXOP == 1 || lpix < GP))
-          outst[(l * NT + (PIXOP == 1 ? lane : lq)) * (TPX + 1) + (w * GP + (PIXOP == 1 ? k : lpix))] = val;
+          put(l, PIXOP == 1 ? lane : lq, w * GP + (PIXOP == 1 ? k : lpix), val);
         continue;
       }
       if (!pv) continue;
@@ -634,9 +647,10 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       const float q12 = (fl & 4) ? q[k][l][2] : 0.0f;
       const float q22 = ((fl & 6) == 6) ? q[k][l][3] : 0.0f;
       const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
-      if (tap) outst[(l * NT + lane) * (TPX + 1) + (w * GP + k)] = val;
+      if (tap) put(l, lane, w * GP + k, val);
     }
   }
+  if constexpr (OUTM != 0) return;
   __syncthreads();
 
   const int nout = p.L * NT * TPX;
@@ -704,12 +718,13 @@ static size_t pyr_lds_bytes(int L, int radius) {
 }
 
 // KIND 0: LDS-DMA staged kernel; 1-3: register-gather kernel (4 px/wave; 2 px/wave with 16- / 32-pixel tiles);
-// 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles)
+// 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles);
+// 6 / 7: KIND 5 with channel-last fp32 / half output (no LDS)
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
-  constexpr int tpx = (KIND == 3 || KIND == 5) ? 32 : TP;
-  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
+  constexpr int tpx = (KIND == 3 || KIND >= 5) ? 32 : TP;
+  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND >= 6 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
@@ -717,8 +732,10 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   else if constexpr (KIND == 2) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false>;
   else if constexpr (KIND == 3) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, false>;
   else if constexpr (KIND == 4) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
-  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
-  const int nthreads = (KIND == 3 || KIND == 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
+  else if constexpr (KIND == 5) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
+  else if constexpr (KIND == 6) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 1>;
+  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 2>;
+  const int nthreads = (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
   static bool attr_set = false;  // idempotent; racing setters write the same value
@@ -745,6 +762,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   const bool probe = (flags & LGU_PYR_PROBE) != 0;
   const bool tiled = (flags & LGU_PYR_TILED) != 0;
   const bool coords_last = (flags & LGU_PYR_COORDS_LAST) != 0;
+  const bool out_nhwc = (flags & LGU_PYR_OUT_NHWC) != 0, out_f16 = (flags & LGU_PYR_OUT_F16) != 0;
+  if (out_f16 && !out_nhwc) return LGU_E_BADARG;
   if (probe && (L < 2 || offsets[1] == nullptr)) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -786,6 +805,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     if (tiled && !(fast && radius == 3 && (variant == 0 || variant == 4 || variant == 5))) return LGU_E_UNSUPPORTED;
     // interleaved coords and slot-indirected volumes are served by the register-gather kernels only
     if ((coords_last || edge_slot) && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
+    // channel-last / half output: production tiled kernel only
+    if (out_nhwc && !(tiled && variant == 0)) return LGU_E_UNSUPPORTED;
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {
@@ -810,7 +831,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       const int slots16 = ((W1 + 15) / 16) * 16, slots32 = ((W1 + 31) / 32) * 32;
       const bool wide = variant == 4 || (variant != 5 && slots32 <= slots16);
 #define LGU_LAUNCH(PR, ZM)                                                                                     \
-  (tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
+  (out_f16 ? launch_fast<3, PR, ZM, 7>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 6>(p, st) :                  \
+   tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
          : variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                                                              \
                         : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);

@@ -1,0 +1,63 @@
+"""Consumer side of the lookup: `UpdateModule.corr_encoder` of the reference
+(droid_slam/droid_net.py:76-80: Conv2d(196,128,1) + ReLU + Conv2d(128,128,3,padding=1) + ReLU), which
+factor_graph.py runs under autocast on the tensor `CorrBlock.__call__` returns.
+
+The dense contractions stay library calls.  What this module adds is the layout hand-over: when the lookup is emitted
+channel-last in half (`CorrBlock.OUT_FORMAT = "nhwc_f16"`, include/lgu_corr.h LGU_PYR_OUT_NHWC | LGU_PYR_OUT_F16) every
+pixel's 196 samples are one contiguous row, so the 1x1 convolution IS a plain (pixels x 196) @ (196 x 128) GEMM: one
+hipBLASLt call with bias and ReLU in its epilogue instead of autocast's cast kernel + MIOpen's convolution + bias +
+ReLU kernels, and the 3x3 convolution then receives the channel-last half tensor MIOpen prefers.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class CorrEncoder:
+    """Drop-in for calling the reference's `corr_encoder` Sequential.
+
+        enc = CorrEncoder(update_module.corr_encoder)
+        corr = enc(corr)            # where droid_net.py:116 has  corr = self.corr_encoder(corr)
+
+    Channel-last half input (E,196,H,W) -> half output (E,128,H,W), channel-last: the values autocast would give,
+    up to the summation order of the half GEMM (fp32 accumulation either way).  Any other input is handed to the
+    wrapped module unchanged (the reference behaviour)."""
+
+    def __init__(self, module):
+        convs = [m for m in module if isinstance(m, torch.nn.Conv2d)]
+        if (len(convs) != 2 or convs[0].kernel_size != (1, 1) or convs[0].bias is None or convs[1].bias is None
+                or convs[1].kernel_size != (3, 3) or convs[1].padding != (1, 1)):
+            raise RuntimeError("CorrEncoder: expected Conv2d(k=1) + ReLU + Conv2d(k=3, padding=1) + ReLU")
+        self.module = module
+        self._convs = convs
+        self._key = None
+
+    def _weights(self):
+        c1, c2 = self._convs
+        key = (c1.weight.data_ptr(), c1.weight._version, c1.bias._version, c2.weight.data_ptr(), c2.weight._version,
+               c2.bias._version)
+        if key != self._key:
+            with torch.no_grad():
+                self._w1t = c1.weight.view(c1.out_channels, c1.in_channels).half().contiguous().t()  # (196,128) view
+                self._b1 = c1.bias.half().contiguous()
+                self._w2 = c2.weight.half().contiguous(memory_format=torch.channels_last)
+                self._b2 = c2.bias.half().contiguous()
+            self._key = key
+        return self._w1t, self._b1, self._w2, self._b2
+
+    @staticmethod
+    def takes(corr):
+        return (corr.is_cuda and corr.dtype == torch.float16 and corr.dim() == 4
+                and corr.permute(0, 2, 3, 1).is_contiguous())
+
+    def __call__(self, corr):
+        if not self.takes(corr) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.module.parameters())):
+            return self.module(corr)
+        w1t, b1, w2, b2 = self._weights()
+        E, C, H, W = corr.shape
+        if C != w1t.shape[0]:
+            raise RuntimeError("CorrEncoder: %d input channels, the encoder takes %d" % (C, w1t.shape[0]))
+        with torch.autocast("cuda", enabled=False):
+            x = corr.permute(0, 2, 3, 1).reshape(E * H * W, C)                     # a view: rows are contiguous
+            h = torch._addmm_activation(b1, x, w1t, use_gelu=False)                # relu(x @ W1^T + b1), one GEMM
+            h = h.view(E, H, W, -1).permute(0, 3, 1, 2)                            # logical NCHW, channel-last
+            return F.relu_(F.conv2d(h, w2, b2, padding=1))

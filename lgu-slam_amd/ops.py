@@ -289,6 +289,30 @@ def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=Non
 
 
 PYR_PROBE, PYR_TILED, PYR_COORDS_LAST = 1, 2, 4  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)
+PYR_OUT_NHWC, PYR_OUT_F16 = 8, 16
+OUT_FORMATS = {"planar": 0, "nhwc": PYR_OUT_NHWC, "nhwc_f16": PYR_OUT_NHWC | PYR_OUT_F16}
+
+
+def _pyr_out(out_format, E, C, H1, W1, device, out):
+    """Output tensor of the fused pyramid sampler, logical shape (E, C, H1, W1) in every format.
+    "planar": contiguous fp32, the reference's tensor (corr.py:109).  "nhwc" / "nhwc_f16": the same values stored
+    channel-last (torch.channels_last strides) in fp32 / half — what the corr_encoder 1x1 convolution that consumes
+    the lookup under autocast wants (droid_net.py:76-80); half = Tensor.half() of the fp32 result, bit for bit."""
+    if out_format not in OUT_FORMATS:
+        raise RuntimeError("out_format must be one of %s" % sorted(OUT_FORMATS))
+    if out_format == "planar":
+        if out is None:
+            return torch.empty((E, C, H1, W1), dtype=torch.float32, device=device)
+        _check(out, "out")
+        return out
+    dt = torch.float16 if out_format == "nhwc_f16" else torch.float32
+    if out is None:
+        return torch.empty((E, H1, W1, C), dtype=dt, device=device).permute(0, 3, 1, 2)
+    if not out.is_cuda:
+        raise RuntimeError("out must be a CUDA tensor")
+    if out.dtype != dt or tuple(out.shape) != (E, C, H1, W1) or not out.permute(0, 2, 3, 1).is_contiguous():
+        raise RuntimeError("out must be a channels-last (E,C,H1,W1) %s tensor for out_format=%r" % (dt, out_format))
+    return out
 TILE_H, TILE_W = 4, 8        # tiled slice layout: 4 x 8 element tiles, one 128-byte line each
 
 
@@ -332,7 +356,7 @@ def _level_dims(volumes, tiled, level_hw):
 
 
 def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=None, tiled=False, level_hw=None,
-                            coords_last=False):
+                            coords_last=False, out_format="planar"):
     """Fused CorrBlock.__call__ body (reference droid_slam/modules/corr.py:88-109): all
     pyramid levels in ONE launch, written straight into the concatenated tensor.
 
@@ -342,6 +366,7 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     tiled=True: volumes are in the tiled slice layout (volume_retile / volume_pyramid(tiled=True));
     level_hw = their logical (H2, W2) when padded.  Same results, fewer HBM lines touched.
     coords_last=True: coords is (E,H1,W1,2), x and y interleaved (no permute pass in front of the lookup).
+    out_format: "planar" (default, the reference's tensor), "nhwc" or "nhwc_f16" (see _pyr_out; tiled pyramids only).
     Returns (E, L*rd*rd, H1, W1).
     """
     L = len(volumes)
@@ -355,17 +380,15 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     E, H1, W1 = volumes[0].shape[:3]
     rd = 2 * radius + 1
     hs, ws = _level_dims(volumes, tiled, level_hw)
-    if out is None:
-        out = torch.empty((E, L * rd * rd, H1, W1), dtype=torch.float32, device=coords.device)
-    else:
-        _check(out, "out")
+    out = _pyr_out(out_format, E, L * rd * rd, H1, W1, coords.device, out)
     if E == 0:
         return out
     vp = (_vp * L)(*[v.data_ptr() for v in volumes])
     op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
     h2 = (ctypes.c_int * L)(*hs)
     w2 = (ctypes.c_int * L)(*ws)
-    flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
+    flags = ((PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
+             | OUT_FORMATS[out_format])
     if tuple(coords.shape) != ((E, H1, W1, 2) if coords_last else (E, 2, H1, W1)):
         raise RuntimeError("defcorr_pyramid_forward: coords must be %s" % ("(E,H1,W1,2)" if coords_last else "(E,2,H1,W1)"))
     with torch.cuda.device(coords.device):
@@ -410,8 +433,9 @@ class DefcorrPyramidPlan:
     every update) and by bench.py so the step is not bound by Python argument handling.
     """
 
-    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False, slots=None):
-        """coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1).
+    def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False, slots=None,
+                 out_format="planar"):
+        """out_format: see _pyr_out.  coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1).
         slots: int32 device tensor (E,): edge e's volume slices live at volumes[l][slots[e]] (the level buffers may
         hold more slots than E); offsets / coords / out stay indexed by e."""
         L = len(volumes)
@@ -427,8 +451,11 @@ class DefcorrPyramidPlan:
             _check_dtype(slots, "slots", torch.int32)
         self._keep = (list(volumes), list(offsets), slots)  # keep the buffers alive
         self.L, self.radius = L, radius
-        self.flags = (PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
-        self.coords_last = coords_last
+        if out_format not in OUT_FORMATS:
+            raise RuntimeError("out_format must be one of %s" % sorted(OUT_FORMATS))
+        self.flags = ((PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
+                      | OUT_FORMATS[out_format])
+        self.coords_last, self.out_format = coords_last, out_format
         self.E, self.H1, self.W1 = volumes[0].shape[:3]
         if slots is not None:
             self.E = slots.shape[0]
@@ -448,8 +475,7 @@ class DefcorrPyramidPlan:
         if tuple(coords.shape) != want:
             raise RuntimeError("coords must be %s" % ("(E,H1,W1,2)" if self.coords_last else "(E,2,H1,W1)"))
         _check(coords, "coords")
-        if out is None:
-            out = torch.empty((self.E, self.channels, self.H1, self.W1), dtype=torch.float32, device=self.device)
+        out = _pyr_out(self.out_format, self.E, self.channels, self.H1, self.W1, self.device, out)
         if self.E == 0:
             return out
         st = torch.cuda.current_stream(self.device).cuda_stream

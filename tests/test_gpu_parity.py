@@ -726,6 +726,63 @@ def test_tiled_pyramid_layout_is_bitwise_the_reference_layout(lgu, oracle, name,
     assert np.abs(host(got) - want_np).max() <= (1e-5 if probe else 1e-6)
 
 
+@pytest.mark.parametrize("fmt", ["nhwc", "nhwc_f16"])
+@pytest.mark.parametrize("probe", [False, True])
+@pytest.mark.parametrize("name", list(TILED_CASES))
+def test_channel_last_output_is_the_planar_output(lgu, name, probe, fmt):
+    """LGU_PYR_OUT_NHWC / LGU_PYR_OUT_F16: the lookup emitted in the consumer convolution's format.  Same values as
+    the reference's planar tensor BIT FOR BIT (fp32), or exactly its Tensor.half() (round-to-nearest-even), with the
+    same offset side effects; the returned tensor has the reference's logical shape and channels-last strides."""
+    seed, E, H1, W1, L, sigma, osc, dense = TILED_CASES[name]
+    case = inputs.pyramid_case(seed, E, H1, W1, L, 3, sigma, osc, dense)
+    hw = [tuple(v.shape[3:]) for v in case["volumes"]]
+    tv = [lgu.ops.volume_retile(dev(v)) for v in case["volumes"]]
+    coords = dev(case["coords"])
+    offs_a = [dev(o) if o is not None else None for o in case["offsets"]]
+    offs_b = [dev(o) if o is not None else None for o in case["offsets"]]
+    want = lgu.ops.defcorr_pyramid_forward(tv, coords, offs_a, 3, probe=probe, tiled=True, level_hw=hw)
+    got = lgu.ops.defcorr_pyramid_forward(tv, coords, offs_b, 3, probe=probe, tiled=True, level_hw=hw, out_format=fmt)
+    assert tuple(got.shape) == tuple(want.shape)
+    assert got.is_contiguous(memory_format=torch.channels_last) or got.permute(0, 2, 3, 1).is_contiguous()
+    if fmt == "nhwc":
+        assert got.dtype == torch.float32 and torch.equal(got, want)
+    else:
+        assert got.dtype == torch.float16 and torch.equal(got, want.half())
+    for a, b in zip(offs_a, offs_b):
+        assert a is None or torch.equal(a, b)
+    # a caller-provided buffer; the slot-indirected entry
+    plan = lgu.ops.DefcorrPyramidPlan(tv, [dev(o) if o is not None else None for o in case["offsets"]], 3, probe=probe,
+                                      tiled=True, level_hw=hw, out_format=fmt,
+                                      slots=torch.arange(E, dtype=torch.int32, device="cuda"))
+    buf = torch.full((E, H1, W1, want.shape[1]), 7.0, dtype=got.dtype, device="cuda").permute(0, 3, 1, 2)
+    assert plan(coords, out=buf) is buf and torch.equal(buf, got)
+
+
+def test_channel_last_output_argument_checks(lgu):
+    v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
+    tv = [lgu.ops.volume_retile(x) for x in v]
+    c = torch.zeros(1, 2, 8, 16, device="cuda")
+    with pytest.raises(lgu._lib.UnsupportedShape):   # row-major pyramid: channel-last output is the tiled kernel's
+        lgu.ops.defcorr_pyramid_forward(v, c, [None, None], 3, out_format="nhwc")
+    with pytest.raises(RuntimeError):
+        lgu.ops.defcorr_pyramid_forward(tv, c, [None, None], 3, tiled=True, out_format="nchw_f16")
+    with pytest.raises(RuntimeError):                # planar buffer handed to a channel-last plan
+        lgu.ops.defcorr_pyramid_forward(tv, c, [None, None], 3, tiled=True, out_format="nhwc",
+                                        out=torch.empty(1, 98, 8, 16, device="cuda"))
+    with pytest.raises(RuntimeError):                # fp32 buffer handed to the half plan
+        lgu.ops.defcorr_pyramid_forward(tv, c, [None, None], 3, tiled=True, out_format="nhwc_f16",
+                                        out=torch.empty(1, 8, 16, 98, device="cuda").permute(0, 3, 1, 2))
+    lib = lgu._lib.load()                            # F16 without NHWC is a bad argument at the C ABI
+    import ctypes
+    vp = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in tv])
+    op = (ctypes.c_void_p * 2)(None, None)
+    hs, ws = (ctypes.c_int * 2)(8, 4), (ctypes.c_int * 2)(16, 8)
+    o = torch.empty(1, 98, 8, 16, device="cuda")
+    rc = lib.lgu_defcorr_pyramid_fwd_f32(vp, ctypes.c_void_p(c.data_ptr()), op, ctypes.c_void_p(o.data_ptr()), 2, 1, 8, 16,
+                                         hs, ws, 3, lgu.ops.PYR_TILED | lgu.ops.PYR_OUT_F16, None)
+    assert rc == lgu._lib.LGU_E_BADARG
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]
@@ -786,6 +843,50 @@ def test_corrblock_layouts_agree_and_cat(lgu, monkeypatch):
         assert a._tiled and float((got - whole(coords)[0]).abs().max()) <= 2e-5
         sub = whole[torch.tensor([0, 2], device="cuda")]
         assert sub(coords[:, [0, 2]])[0].shape == (1, 2, 196, h, w)
+
+
+def test_corrblock_out_format_and_corr_encoder(lgu, monkeypatch):
+    """SURVEY f4 hand-over: CorrBlock.OUT_FORMAT = "nhwc_f16" returns the reference's logical (1,E,196,h,w) tensor
+    as channel-last half = .half() of the planar result (to the 2e-5 two constructions differ by, see above), same
+    persistent mask state; CorrEncoder over it == the reference's corr_encoder Sequential under autocast on the
+    planar tensor (droid_net.py:76-80,116), to half rounding, and == the fp32 evaluation of the same op to 2e-3."""
+    torch.manual_seed(9)
+    E, h, w = 3, 24, 32
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    GA = lgu.GaussianMask(h, w).cuda()
+    enc = torch.nn.Sequential(torch.nn.Conv2d(196, 128, 1), torch.nn.ReLU(inplace=True),
+                              torch.nn.Conv2d(128, 128, 3, padding=1), torch.nn.ReLU(inplace=True)).cuda().eval()
+    f1 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device="cuda") * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda").float(), torch.arange(w, device="cuda").float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, h, w, 2, device="cuda")
+    with torch.no_grad():
+        outs = {}
+        for fmt in ("planar", "nhwc", "nhwc_f16"):
+            monkeypatch.setattr(lgu.CorrBlock, "OUT_FORMAT", fmt)
+            blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+            outs[fmt] = [blk(coords)[0], blk(coords)[0]]
+            for o in outs[fmt]:
+                assert tuple(o.shape) == (1, E, 196, h, w)
+        for k in range(2):
+            assert outs["nhwc"][k].dtype == torch.float32
+            assert float((outs["nhwc"][k] - outs["planar"][k]).abs().max()) <= 2e-5
+            assert outs["nhwc_f16"][k].dtype == torch.float16
+            tol = 2e-5 + outs["planar"][k].abs() * 2.0 ** -11
+            assert bool(((outs["nhwc_f16"][k].float() - outs["planar"][k]).abs() <= tol + 6e-8).all())
+        planar, cl16 = outs["planar"][0].view(E, 196, h, w), outs["nhwc_f16"][0].view(E, 196, h, w)
+        fused = lgu.CorrEncoder(enc)
+        assert fused.takes(cl16) and not fused.takes(planar)
+        got = fused(cl16)
+        assert got.dtype == torch.float16 and tuple(got.shape) == (E, 128, h, w)
+        with torch.autocast("cuda", dtype=torch.float16):
+            want = enc(planar)
+        exact = enc(cl16.float())                      # the same op in fp32 on the half inputs
+        scale = float(exact.abs().max())
+        assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -9 * scale
+        assert float((got.float() - exact).abs().max()) <= 2e-3 * scale
+        assert torch.equal(fused(planar), enc(planar))  # anything else goes to the wrapped module unchanged
 
 
 @pytest.mark.parametrize("half", [True, False])

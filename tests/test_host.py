@@ -228,3 +228,22 @@ def test_lowmem_plan_argument_checks(lgu):
         ops.LowmemPyramidPlan(h, [h], [None], 3)
     with pytest.raises(RuntimeError, match="no CPU fallback|expected scalar type"):
         ops.LowmemPyramidPlan(h.float(), [h], [None], 3)
+
+
+def test_corr_encoder_host_logic():
+    """CorrEncoder: structure check, and anything that is not a channel-last half CUDA tensor is handed to
+    the wrapped module unchanged (the reference call, droid_net.py:116)."""
+    import lgu_slam_amd as lgu
+    torch.manual_seed(0)
+    enc = torch.nn.Sequential(torch.nn.Conv2d(196, 128, 1), torch.nn.ReLU(inplace=True),
+                              torch.nn.Conv2d(128, 128, 3, padding=1), torch.nn.ReLU(inplace=True)).eval()
+    fused = lgu.CorrEncoder(enc)
+    x = torch.randn(2, 196, 6, 8)
+    assert not fused.takes(x) and not fused.takes(x.half().contiguous(memory_format=torch.channels_last))
+    with torch.no_grad():
+        assert torch.equal(fused(x), enc(x))
+    with pytest.raises(RuntimeError):
+        lgu.CorrEncoder(torch.nn.Sequential(torch.nn.Conv2d(196, 128, 3), torch.nn.ReLU()))
+    with pytest.raises(RuntimeError):
+        lgu.ops.DefcorrPyramidPlan.__init__(object.__new__(lgu.ops.DefcorrPyramidPlan), [], [], 3, out_format="nchw")
+    assert lgu.CorrBlock.OUT_FORMAT == "planar" and set(lgu.ops.OUT_FORMATS) == {"planar", "nhwc", "nhwc_f16"}
