@@ -131,6 +131,22 @@ int lgu_defcorr_pyramid_slots_fwd_f32(const float* const* volumes, const int* ed
                                       int L, int E, int H1, int W1, const int* H2, const int* W2,
                                       int radius, int flags, void* stream);
 
+/* The lookup with its consumer fused in: lgu_defcorr_pyramid_slots_fwd_f32 followed by the first layer of
+ * UpdateModule.corr_encoder (reference droid_slam/droid_net.py:76-77,116: Conv2d(L*rd*rd, 128, 1) + ReLU, evaluated
+ * under autocast: half inputs and weights, fp32 accumulation, half result) on the matrix cores, in the same launch:
+ *   out (E, H1, W1, enc_n) IEEE half, channel-last = relu(W1 . half(samples) + b1) per pixel
+ * so the L*rd*rd samples of a pixel never go to HBM.
+ *   enc_w  half (enc_n, Kp): the convolution weight (enc_n, L*rd*rd, 1, 1) with every row zero-padded to
+ *          Kp = ceil(L*rd*rd / 32) * 32 entries, 16-byte aligned;   enc_b  half (enc_n).
+ * edge_slot may be NULL (slot e = edge e).  flags: LGU_PYR_TILED is required; LGU_PYR_PROBE and LGU_PYR_COORDS_LAST as
+ * above; the LGU_PYR_OUT_* flags do not apply (LGU_E_BADARG).  Served for radius 3, enc_n = 128, zero-offset patterns
+ * the sampler handles in one launch (none / all / levels >= 2); otherwise LGU_E_UNSUPPORTED.  Offsets get the same in-place side
+ * effects as in the unfused entry. */
+int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge_slot, const float* coords,
+                                    float* const* offsets, const void* enc_w, const void* enc_b, void* out,
+                                    int L, int E, int H1, int W1, const int* H2, const int* W2,
+                                    int radius, int enc_n, int flags, void* stream);
+
 /* Fused volume post-processing of CorrBlock.__init__ (reference droid_slam/gaussianMask_cuda.py:84-86
  * and droid_slam/modules/corr.py:79-86): in ONE pass over the raw all-pairs volume
  *   level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(covs.x*covs.y)) + volume

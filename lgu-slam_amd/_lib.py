@@ -49,6 +49,8 @@ SIGNATURES = {
     "lgu_ba_pose_retr_f32": [_vp] * 2 + [_int] * 2 + [_vp],
     "lgu_ba_disp_retr_f32": [_vp] * 3 + [_int] * 2 + [_vp],
     "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],
+    "lgu_defcorr_pyramid_enc_fwd_f32": [ctypes.POINTER(_vp), _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _int, _int, _int,
+                                        _int, ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp],
 }
 
 _lib = None

@@ -106,6 +106,9 @@ class CorrBlock:
 
     TILED_PYRAMID = True
     OUT_FORMAT = "planar"
+    ENCODER = None   # a lgu_slam_amd.encoder.CorrEncoder: its first layer (1x1 convolution + ReLU) then runs INSIDE the
+                     # lookup launch and __call__ returns the (1,E,128,H,W) half result of that layer; the same
+                     # CorrEncoder, called on it, applies only the remaining 3x3 convolution
 
     def __init__(self, ofsMap, ofs_residual, GA, fmap1, fmap2, num_levels=4, radius=3):
         self.num_levels = num_levels
@@ -240,13 +243,14 @@ class CorrBlock:
         # scaled in place by the kernel (the same persistent state as above).  The prepared
         # launch is rebuilt only when the pyramid / offset buffers change (cat, __getitem__).
         fmt = CorrBlock.OUT_FORMAT if self._tiled else "planar"
+        enc = CorrBlock.ENCODER.fused_operands(self.num_levels * rd * rd) if (CorrBlock.ENCODER is not None and self._tiled) else None
         key = tuple(t.data_ptr() for t in pyr) + tuple(o.data_ptr() if o is not None else 0 for o in offs) + \
-            ((slots.data_ptr(), slots.shape[0]) if slots is not None else ()) + (fmt,)
+            ((slots.data_ptr(), slots.shape[0]) if slots is not None else ()) + (fmt, enc[0].data_ptr() if enc else 0)
         try:
             if getattr(self, "_plan_key", None) != key:
                 self._plan = ops.DefcorrPyramidPlan(pyr, offs, self.radius, probe=True, tiled=self._tiled,
                                                     level_hw=self._level_hw, coords_last=True, slots=slots,
-                                                    out_format=fmt)
+                                                    out_format=fmt, encoder=enc)
                 self._plan_key = key
             out = self._plan(coords_xy if coords_xy.is_contiguous() else coords_xy.contiguous())
         except _lib.UnsupportedShape:

@@ -57,7 +57,21 @@ struct PyrParams {
   // optional storage indirection: edge e's volume slices live at slot edge_slot[e] of the level buffers (the state
   // container appends / drops edges without moving the pyramid); null = slot e.  Offsets, coords, out stay by e.
   const int* edge_slot;
+  // fused consumer (OUTM 3): the first layer of corr_encoder, relu(W1 x + b1), applied to every pixel's Ctot samples
+  const void* enc_w;  // half (ENC_N, enc_kp): W1 rows zero-padded from Ctot to enc_kp = ceil(Ctot / 32) * 32 entries
+  const void* enc_b;  // half (ENC_N)
+  int enc_kp;
 };
+
+constexpr int ENC_N = 128;       // output channels of the fused 1x1 convolution (UpdateModule.corr_encoder[0])
+constexpr int ENC_XPITCH = 200;  // halves per pixel row of the LDS operand tile: 100 dwords -> the 16 rows of a fragment
+                                 // read start 36 banks apart, conflict-free
+constexpr int ENC_MAXKS = 7;     // k-steps of 32: up to 224 input channels (4 levels x 49 taps = 196)
+constexpr int ENC_XBYTES = (32 * ENC_XPITCH + 64) * 2;             // operand tile (+ the over-read of the last row)
+constexpr int ENC_LDS_BYTES = ENC_XBYTES + 8 * ENC_MAXKS * 1024;   // + the weight fragments: 70 272 bytes, 2 workgroups per CU
+typedef _Float16 enc_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 enc_half4 __attribute__((ext_vector_type(4)));
+typedef float enc_f32x4 __attribute__((ext_vector_type(4)));
 
 // Position of target element (y, x) inside a slice.  Reference layout: row-major H2 x W2.
 // Tiled layout (LGU_PYR_TILED): 4 x 8 element tiles = one 128-byte line each, tiles row-major over the slice
@@ -420,6 +434,11 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // tile; 1 / 2 = channel-last (E, H1, W1, L*NT) in fp32 / half (LGU_PYR_OUT_NHWC [| LGU_PYR_OUT_F16]) — the form the
 // consumer 1x1 convolution of the update operator prefers (droid_net.py:76-80 under autocast).  With lanes = taps a
 // wave's store is already one contiguous run of the pixel's channels, so these forms need no LDS and no barrier.
+// 3 = the consumer fused in (lgu_defcorr_pyramid_enc_fwd_f32): the samples of the workgroup's 32 pixels are parked in LDS
+// as half rows (the cast autocast applies) and multiplied by the first corr_encoder layer on the matrix cores —
+// v_mfma_f32_16x16x32_f16, A = 16 output channels of W1 (16 contiguous bytes per lane from the zero-padded weight
+// rows), B = 16 pixels of the LDS tile, one 16 x 16 output tile per wave (8 channel tiles x 2 pixel tiles = the 16
+// waves), fp32 accumulation, + bias, ReLU, half — and only the (E, H1, W1, 128) half result goes to HBM.
 template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED, int OUTM = 0>
 __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
@@ -452,6 +471,20 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
   const size_t HW1 = (size_t)p.H1 * p.W1;
   const size_t row_pix = ((size_t)e * p.H1 + y) * p.W1;
   const size_t vrow_pix = p.edge_slot ? ((size_t)p.edge_slot[e] * p.H1 + y) * p.W1 : row_pix;  // where the volume slices live
+
+  if constexpr (OUTM == 3) {
+    // The weight matrix goes to LDS by LDS-DMA right away: no registers, and its latency is over long before the
+    // gathers are.  Fragment order: chunk (channel tile mt, k-step ks) = 1 KiB, lane i of the DMA instruction supplies
+    // the 16 bytes lane i of the MFMA will want (row mt*16 + i%16, k = ks*32 + (i/16)*8), so the read-back is
+    // lane-linear (conflict-free).  Channel tile mt is fetched by waves mt (k-steps 0-3) and mt+8 (4-6).
+    const int mt = w & 7, nks = p.enc_kp >> 5;
+    char* const wl = reinterpret_cast<char*>(lds4) + ENC_XBYTES + mt * (ENC_MAXKS * 1024);
+    const char* const wg = reinterpret_cast<const char*>(p.enc_w) + ((size_t)(mt * 16 + (lane & 15)) * p.enc_kp + (lane >> 4) * 8) * 2;
+#pragma unroll
+    for (int ks = 0; ks < ENC_MAXKS; ks++)
+      if (ks < nks && (ks < 4) == (w < 8))
+        __builtin_amdgcn_global_load_lds((glb_void*)(wg + ks * 64), (lds_void*)(wl + ks * 1024), 16, 0, 0);
+  }
 
   // ---- phase 0: coords + offsets ----
   float x0[GP], y0[GP];
@@ -606,6 +639,8 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
   auto put = [&](int l, int ch, int pc, float val) __attribute__((always_inline)) {
     if constexpr (OUTM == 0) {
       outst[(l * NT + ch) * (TPX + 1) + pc] = val;
+    } else if constexpr (OUTM == 3) {
+      reinterpret_cast<_Float16*>(lds4)[pc * ENC_XPITCH + l * NT + ch] = (_Float16)val;
     } else {
       const size_t o = (row_pix + xbase + pc) * (size_t)p.Ctot + p.cbase + l * NT + ch;
       if constexpr (OUTM == 1) p.out[o] = val;
@@ -649,6 +684,41 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
       if (tap) put(l, lane, w * GP + k, val);
     }
+  }
+  if constexpr (OUTM == 3) {
+    static_assert(OUTM != 3 || (TPX == 32 && GP == 2), "fused encoder: 32-pixel tiles, 16 waves");
+    const int mt = w & 7, ntile = w >> 3;  // channel tile, pixel tile of this wave
+    const int lr = lane & 15, kg = lane >> 4;
+    const int nks = p.enc_kp >> 5;
+    const enc_half4 bias = *reinterpret_cast<const enc_half4*>(reinterpret_cast<const _Float16*>(p.enc_b) + mt * 16 + kg * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's weight DMA (the compiler does not track it)
+    __syncthreads();
+    const char* const wl = reinterpret_cast<const char*>(lds4) + ENC_XBYTES + mt * (ENC_MAXKS * 1024) + lane * 16;
+    const _Float16* xrow = reinterpret_cast<const _Float16*>(lds4) + (ntile * 16 + lr) * ENC_XPITCH + kg * 8;
+    // Entries at k >= Ctot of the last k-step are not this pixel's samples (row padding / the next row).  W1 is zero
+    // there, but 0 * NaN is NaN, so they are cleared on the B side as well: one 128-bit lane mask, built once.
+    typedef unsigned enc_u32x4 __attribute__((ext_vector_type(4)));
+    const int nvalid = p.Ctot - ((nks - 1) * 32 + kg * 8);  // valid entries of this lane's 8 in the last k-step
+    enc_u32x4 lastmask;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lastmask[j] = nvalid >= 2 * j + 2 ? 0xffffffffu : nvalid == 2 * j + 1 ? 0x0000ffffu : 0u;
+    enc_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ks = 0; ks < ENC_MAXKS; ks++) {
+      if (ks >= nks) break;
+      const enc_half8 a = *reinterpret_cast<const enc_half8*>(wl + ks * 1024);
+      enc_half8 b = *reinterpret_cast<const enc_half8*>(xrow + ks * 32);
+      if (ks == nks - 1) b = __builtin_bit_cast(enc_half8, __builtin_bit_cast(enc_u32x4, b) & lastmask);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+    const int pxo = xbase + ntile * 16 + lr;
+    if (pxo < p.W1) {
+      enc_half4 o;
+#pragma unroll
+      for (int t = 0; t < 4; t++) o[t] = (_Float16)fmaxf(acc[t] + (float)bias[t], 0.0f);
+      *reinterpret_cast<enc_half4*>(reinterpret_cast<_Float16*>(p.out) + (row_pix + pxo) * ENC_N + mt * 16 + kg * 4) = o;
+    }
+    return;
   }
   if constexpr (OUTM != 0) return;
   __syncthreads();
@@ -719,12 +789,13 @@ static size_t pyr_lds_bytes(int L, int radius) {
 
 // KIND 0: LDS-DMA staged kernel; 1-3: register-gather kernel (4 px/wave; 2 px/wave with 16- / 32-pixel tiles);
 // 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles);
-// 6 / 7: KIND 5 with channel-last fp32 / half output (no LDS)
+// 6 / 7: KIND 5 with channel-last fp32 / half output (no LDS); 8: KIND 5 with the fused corr_encoder layer
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
   constexpr int tpx = (KIND == 3 || KIND >= 5) ? 32 : TP;
-  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND >= 6 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
+  const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
+                     : KIND >= 6 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
@@ -734,7 +805,8 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   else if constexpr (KIND == 4) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
   else if constexpr (KIND == 5) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
   else if constexpr (KIND == 6) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 1>;
-  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 2>;
+  else if constexpr (KIND == 7) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 2>;
+  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
   const int nthreads = (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
@@ -753,8 +825,11 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 // Host dispatcher shared by the three forward entry points.
 static int pyramid_forward(const float* const* volumes, const float* coords, float* const* offsets, float* out,
                            int L, int E, int H1, int W1, const int* H2, const int* W2, int radius, int flags,
-                           void* stream, const int* edge_slot = nullptr) {
+                           void* stream, const int* edge_slot = nullptr, const void* enc_w = nullptr,
+                           const void* enc_b = nullptr, int enc_n = 0) {
   if (!volumes || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
+  const bool enc = enc_w != nullptr;
+  if (enc && (!enc_b || (flags & (LGU_PYR_OUT_NHWC | LGU_PYR_OUT_F16)))) return LGU_E_BADARG;
   if (L < 1 || L > LGU_MAX_LEVELS || E < 0 || H1 < 1 || W1 < 1 || radius < 0 || radius > LGU_MAX_RADIUS)
     return LGU_E_BADARG;
   for (int l = 0; l < L; l++)
@@ -807,6 +882,10 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     if ((coords_last || edge_slot) && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
     // channel-last / half output: production tiled kernel only
     if (out_nhwc && !(tiled && variant == 0)) return LGU_E_UNSUPPORTED;
+    // fused encoder layer: production tiled kernel, all levels in this one launch, 128 output channels
+    if (enc && !(tiled && variant == 0 && nl == L && enc_n == ENC_N && aligned16(enc_w) && aligned16(out) &&
+                 (reinterpret_cast<uintptr_t>(enc_b) & 7) == 0))
+      return LGU_E_UNSUPPORTED;
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {
@@ -819,6 +898,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
         p.ssz[l] = tiled ? ((p.H2[l] + 3) >> 2) * p.tpr[l] * 32 : p.H2[l] * p.W2[l];
       }
       p.coords = coords; p.out = out; p.edge_slot = edge_slot;
+      p.enc_w = enc_w; p.enc_b = enc_b; p.enc_kp = ((Ctot + 31) / 32) * 32;
       p.L = nl; p.E = E; p.H1 = H1; p.W1 = W1;
       p.tiles_per_row = (W1 + TP - 1) / TP;
       p.Ctot = Ctot; p.cbase = l0 * nt; p.lbase = l0; p.flags = flags;
@@ -831,7 +911,8 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       const int slots16 = ((W1 + 15) / 16) * 16, slots32 = ((W1 + 31) / 32) * 32;
       const bool wide = variant == 4 || (variant != 5 && slots32 <= slots16);
 #define LGU_LAUNCH(PR, ZM)                                                                                     \
-  (out_f16 ? launch_fast<3, PR, ZM, 7>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 6>(p, st) :                  \
+  (enc ? launch_fast<3, PR, ZM, 8>(p, st) :                                                                    \
+   out_f16 ? launch_fast<3, PR, ZM, 7>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 6>(p, st) :                  \
    tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
          : variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                                                              \
                         : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
@@ -871,6 +952,15 @@ int lgu_defcorr_pyramid_slots_fwd_f32(const float* const* volumes, const int* ed
                                       float* const* offsets, float* out, int L, int E, int H1, int W1, const int* H2,
                                       const int* W2, int radius, int flags, void* stream) {
   return lgu::pyramid_forward(volumes, coords, offsets, out, L, E, H1, W1, H2, W2, radius, flags, stream, edge_slot);
+}
+
+int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge_slot, const float* coords,
+                                    float* const* offsets, const void* enc_w, const void* enc_b, void* out, int L, int E,
+                                    int H1, int W1, const int* H2, const int* W2, int radius, int enc_n, int flags,
+                                    void* stream) {
+  if (!enc_w || !enc_b) return LGU_E_BADARG;
+  return lgu::pyramid_forward(volumes, coords, offsets, reinterpret_cast<float*>(out), L, E, H1, W1, H2, W2, radius, flags,
+                              stream, edge_slot, enc_w, enc_b, enc_n);
 }
 
 int lgu_defcorr_fwd_f32(const float* volume, const float* coords, float* offset, float* corr, int E, int H1, int W1,

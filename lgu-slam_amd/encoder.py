@@ -20,7 +20,11 @@ class CorrEncoder:
 
     Channel-last half input (E,196,H,W) -> half output (E,128,H,W), channel-last: the values autocast would give,
     up to the summation order of the half GEMM (fp32 accumulation either way).  Any other input is handed to the
-    wrapped module unchanged (the reference behaviour)."""
+    wrapped module unchanged (the reference behaviour).
+
+    With `CorrBlock.ENCODER = enc` the first layer runs inside the lookup launch (lgu_defcorr_pyramid_enc_fwd_f32, the
+    196 samples never reach HBM); the lookup then returns that layer's (E,128,H,W) half output, which this object
+    recognises by its channel count and only finishes (3x3 convolution + ReLU)."""
 
     def __init__(self, module):
         convs = [m for m in module if isinstance(m, torch.nn.Conv2d)]
@@ -44,6 +48,19 @@ class CorrEncoder:
             self._key = key
         return self._w1t, self._b1, self._w2, self._b2
 
+    def fused_operands(self, in_channels):
+        """(w, b) for ops.DefcorrPyramidPlan(encoder=...), or None when the lookup's channel count is not this
+        encoder's (then the lookup stays unfused)."""
+        c1 = self._convs[0]
+        if in_channels != c1.in_channels or c1.out_channels != 128 or not c1.weight.is_cuda:
+            return None
+        key = (c1.weight.data_ptr(), c1.weight._version, c1.bias._version)
+        if getattr(self, "_fkey", None) != key:
+            from . import ops
+            self._fused = ops.pack_encoder_layer(c1.weight, c1.bias)
+            self._fkey = key
+        return self._fused
+
     @staticmethod
     def takes(corr):
         return (corr.is_cuda and corr.dtype == torch.float16 and corr.dim() == 4
@@ -54,6 +71,9 @@ class CorrEncoder:
             return self.module(corr)
         w1t, b1, w2, b2 = self._weights()
         E, C, H, W = corr.shape
+        if C == w1t.shape[1] and C != w1t.shape[0]:  # first layer already applied inside the lookup launch
+            with torch.autocast("cuda", enabled=False):
+                return F.relu_(F.conv2d(corr, w2, b2, padding=1))
         if C != w1t.shape[0]:
             raise RuntimeError("CorrEncoder: %d input channels, the encoder takes %d" % (C, w1t.shape[0]))
         with torch.autocast("cuda", enabled=False):

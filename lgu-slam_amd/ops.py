@@ -426,6 +426,22 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+ENC_N = 128  # output channels of the fused corr_encoder layer (csrc/defcorr.hip)
+
+
+def pack_encoder_layer(weight, bias):
+    """Operands of the fused lookup + first corr_encoder layer (lgu_defcorr_pyramid_enc_fwd_f32) from the 1x1
+    convolution's parameters (reference droid_net.py:76-77): the (128, K, 1, 1) weight as half rows zero-padded to a
+    multiple of 32 entries, the bias as half.  Returns (w (128, Kp) half, b (128,) half)."""
+    n, k = weight.shape[0], weight.shape[1]
+    if n != ENC_N or weight.numel() != n * k or bias is None or bias.numel() != n:
+        raise RuntimeError("pack_encoder_layer: expected a (%d, K, 1, 1) convolution weight with bias" % ENC_N)
+    kp = -(-k // 32) * 32
+    w = torch.zeros((n, kp), dtype=torch.float16, device=weight.device)
+    w[:, :k] = weight.detach().reshape(n, k).half()
+    return w, bias.detach().half().contiguous()
+
+
 class DefcorrPyramidPlan:
     """Prepared launch of the fused pyramid sampler for a fixed pyramid / offset set: the
     pointer and size tables are built once, a call costs one ctypes invocation.  Used by
@@ -434,8 +450,10 @@ class DefcorrPyramidPlan:
     """
 
     def __init__(self, volumes, offsets, radius, probe=False, tiled=False, level_hw=None, coords_last=False, slots=None,
-                 out_format="planar"):
-        """out_format: see _pyr_out.  coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1).
+                 out_format="planar", encoder=None):
+        """out_format: see _pyr_out.  encoder = (w, b) from pack_encoder_layer: the first corr_encoder layer runs in the
+        same launch and the call returns relu(W1 . half(samples) + b1) as a channel-last half (E,128,H1,W1) tensor
+        (tiled pyramids only; out_format is then ignored).  coords_last=True: calls take coords as (E,H1,W1,2) (x, y interleaved) instead of (E,2,H1,W1).
         slots: int32 device tensor (E,): edge e's volume slices live at volumes[l][slots[e]] (the level buffers may
         hold more slots than E); offsets / coords / out stay indexed by e."""
         L = len(volumes)
@@ -456,6 +474,17 @@ class DefcorrPyramidPlan:
         self.flags = ((PYR_PROBE if probe else 0) | (PYR_TILED if tiled else 0) | (PYR_COORDS_LAST if coords_last else 0)
                       | OUT_FORMATS[out_format])
         self.coords_last, self.out_format = coords_last, out_format
+        self._enc = None
+        if encoder is not None:
+            w, b = encoder
+            kp = -(-(L * (2 * radius + 1) ** 2) // 32) * 32
+            if (w.dtype != torch.float16 or b.dtype != torch.float16 or tuple(w.shape) != (ENC_N, kp)
+                    or tuple(b.shape) != (ENC_N,) or not (w.is_cuda and b.is_cuda and w.is_contiguous() and b.is_contiguous())):
+                raise RuntimeError("encoder must be pack_encoder_layer(...) operands for %d input channels" % (L * (2 * radius + 1) ** 2))
+            self._enc = (w, b)
+            self.flags &= ~(PYR_OUT_NHWC | PYR_OUT_F16)
+            self.out_format = "nhwc_f16"
+            self._fn_enc = _lib.load().lgu_defcorr_pyramid_enc_fwd_f32
         self.E, self.H1, self.W1 = volumes[0].shape[:3]
         if slots is not None:
             self.E = slots.shape[0]
@@ -475,11 +504,15 @@ class DefcorrPyramidPlan:
         if tuple(coords.shape) != want:
             raise RuntimeError("coords must be %s" % ("(E,H1,W1,2)" if self.coords_last else "(E,2,H1,W1)"))
         _check(coords, "coords")
-        out = _pyr_out(self.out_format, self.E, self.channels, self.H1, self.W1, self.device, out)
+        out = _pyr_out(self.out_format, self.E, ENC_N if self._enc else self.channels, self.H1, self.W1, self.device, out)
         if self.E == 0:
             return out
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if self._slots is not None:
+        if self._enc is not None:
+            rc = self._fn_enc(self._vp, self._slots, coords.data_ptr(), self._op, self._enc[0].data_ptr(),
+                              self._enc[1].data_ptr(), out.data_ptr(), self.L, self.E, self.H1, self.W1, self._h2, self._w2,
+                              self.radius, ENC_N, self.flags, st)
+        elif self._slots is not None:
             rc = self._fn_slots(self._vp, self._slots, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1,
                                 self.W1, self._h2, self._w2, self.radius, self.flags, st)
         else:

@@ -845,6 +845,55 @@ def test_corrblock_layouts_agree_and_cat(lgu, monkeypatch):
         assert sub(coords[:, [0, 2]])[0].shape == (1, 2, 196, h, w)
 
 
+@pytest.mark.parametrize("probe", [False, True])
+@pytest.mark.parametrize("name", list(TILED_CASES))
+def test_fused_encoder_layer_is_the_layer_on_the_half_lookup(lgu, name, probe):
+    """lgu_defcorr_pyramid_enc_fwd_f32: lookup + first corr_encoder layer in one launch == relu(W1 . x + b1) evaluated
+    in fp32 on x = the half lookup (LGU_PYR_OUT_F16, itself bit-exact against the planar tensor) with the half weights,
+    rounded to half: half products are exact in fp32 and accumulation is fp32 on both sides, so the difference is
+    summation order + one half rounding (tolerance 2^-10 relative + 1e-4 absolute).  Channel counts 196 / 147 / 98
+    exercise the K padding (224 / 160 / 128); W1 = 40 and 24 the partial 32-pixel tile.  Same offset side effects."""
+    seed, E, H1, W1, L, sigma, osc, dense = TILED_CASES[name]
+    case = inputs.pyramid_case(seed, E, H1, W1, L, 3, sigma, osc, dense)
+    hw = [tuple(v.shape[3:]) for v in case["volumes"]]
+    tv = [lgu.ops.volume_retile(dev(v)) for v in case["volumes"]]
+    coords = dev(case["coords"])
+    offs_a = [dev(o) if o is not None else None for o in case["offsets"]]
+    offs_b = [dev(o) if o is not None else None for o in case["offsets"]]
+    K = L * 49
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    conv_w = torch.randn(128, K, 1, 1, device="cuda", generator=g) * 0.5
+    conv_b = torch.randn(128, device="cuda", generator=g) * 0.1
+    w, b = lgu.ops.pack_encoder_layer(conv_w, conv_b)
+    assert tuple(w.shape) == (128, -(-K // 32) * 32) and float(w[:, K:].abs().max() if w.shape[1] > K else 0.0) == 0.0
+    x = lgu.ops.defcorr_pyramid_forward(tv, coords, offs_a, 3, probe=probe, tiled=True, level_hw=hw, out_format="nhwc_f16")
+    plan = lgu.ops.DefcorrPyramidPlan(tv, offs_b, 3, probe=probe, tiled=True, level_hw=hw, encoder=(w, b))
+    got = plan(coords)
+    assert got.dtype == torch.float16 and tuple(got.shape) == (E, 128, H1, W1) and got.permute(0, 2, 3, 1).is_contiguous()
+    want = torch.relu(x.permute(0, 2, 3, 1).float() @ w[:, :K].float().t() + b.float()).permute(0, 3, 1, 2)
+    err = (got.float() - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -10 + 1e-4).all()), float(err.max())
+    assert float(want.max()) > 0.05   # the comparison is not vacuous
+    for a_, b_ in zip(offs_a, offs_b):
+        assert a_ is None or torch.equal(a_, b_)
+
+
+def test_fused_encoder_argument_checks(lgu):
+    v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
+    tv = [lgu.ops.volume_retile(x) for x in v]
+    c = torch.zeros(1, 2, 8, 16, device="cuda")
+    w, b = lgu.ops.pack_encoder_layer(torch.randn(128, 98, 1, 1, device="cuda"), torch.randn(128, device="cuda"))
+    with pytest.raises(lgu._lib.UnsupportedShape):   # row-major pyramid
+        lgu.ops.DefcorrPyramidPlan(v, [None, None], 3, encoder=(w, b))(c)
+    with pytest.raises(RuntimeError):                # weight rows packed for another channel count
+        lgu.ops.DefcorrPyramidPlan(tv, [None, None], 3, tiled=True, encoder=(w[:, :96].contiguous(), b))
+    with pytest.raises(RuntimeError):
+        lgu.ops.pack_encoder_layer(torch.randn(64, 98, 1, 1, device="cuda"), torch.randn(64, device="cuda"))
+    got = lgu.ops.DefcorrPyramidPlan(tv, [None, None], 3, tiled=True, encoder=(w, b))(c)
+    assert tuple(got.shape) == (1, 128, 8, 16)
+
+
 def test_corrblock_out_format_and_corr_encoder(lgu, monkeypatch):
     """SURVEY f4 hand-over: CorrBlock.OUT_FORMAT = "nhwc_f16" returns the reference's logical (1,E,196,h,w) tensor
     as channel-last half = .half() of the planar result (to the 2e-5 two constructions differ by, see above), same
@@ -887,6 +936,15 @@ def test_corrblock_out_format_and_corr_encoder(lgu, monkeypatch):
         assert float((got.float() - want.float()).abs().max()) <= 2.0 ** -9 * scale
         assert float((got.float() - exact).abs().max()) <= 2e-3 * scale
         assert torch.equal(fused(planar), enc(planar))  # anything else goes to the wrapped module unchanged
+        # first layer inside the lookup launch: CorrBlock returns the 128-channel half tensor, CorrEncoder finishes it
+        monkeypatch.setattr(lgu.CorrBlock, "ENCODER", fused)
+        blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        mid = blk(coords)[0]
+        assert tuple(mid.shape) == (1, E, 128, h, w) and mid.dtype == torch.float16
+        got2 = fused(mid.view(E, 128, h, w))
+        assert tuple(got2.shape) == (E, 128, h, w)
+        assert float((got2.float() - want.float()).abs().max()) <= 2.0 ** -9 * scale
+        assert float((got2.float() - exact).abs().max()) <= 2e-3 * scale
 
 
 @pytest.mark.parametrize("half", [True, False])

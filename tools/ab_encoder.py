@@ -116,6 +116,26 @@ def main():
                "encoder_out_abs_max": float(base.abs().max())}
         print(json.dumps(rec), flush=True)
 
+    # first layer inside the lookup launch (lgu_defcorr_pyramid_enc_fwd_f32): the 196 samples never reach HBM
+    fplan = ops.DefcorrPyramidPlan(tv, [o.clone() if o is not None else None for o in offs], R, tiled=True,
+                                   level_hw=level_hw, encoder=ops.pack_encoder_layer(enc[0].weight, enc[0].bias))
+    fout = ops._pyr_out("nhwc_f16", E, 128, H1, W1, dev, None)
+
+    def ffirst():
+        return fplan(coords, out=fout)
+
+    def fwhole():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return enc_cl[3](enc_cl[2](ffirst()))
+
+    y = fwhole().float()
+    print(json.dumps({"out_format": "first encoder layer fused into the lookup launch (matrix cores)", "edges": E,
+                      "lookup_plus_conv1x1_ms": dev_time(ffirst, args.reps),
+                      "lookup_plus_corr_encoder_ms": dev_time(fwhole, args.reps),
+                      "encoder_out_max_abs_diff_vs_planar": float((y - base).abs().max()),
+                      "encoder_out_abs_max": float(base.abs().max())}), flush=True)
+
 
 if __name__ == "__main__":
     main()
+
