@@ -404,13 +404,13 @@ def main():
         A, U = algorithmic_bytes_per_unit(rowmajor_vols if tiled else vols, coords, offs, R)
         if args.out_format == "nhwc_f16":  # the output row is 2-byte elements
             A -= L * (2 * R + 1) ** 2 * 2
-        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
+        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
                  5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
                  3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
                  2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
         kname = kname.replace("LAYOUT", "true" if tiled else "false")
-        if args.out_format != "planar":
-            kname = kname[:-1] + (",1>" if args.out_format == "nhwc" else ",2>")
+        if args.out_format != "planar":  # channel-last forms: 8-pixel tiles
+            kname = kname.replace(",2,16,", ",2,8,")[:-1] + (",1>" if args.out_format == "nhwc" else ",2>")
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
         # because counters cannot be collected from inside the timed process; see profiles/.

@@ -63,6 +63,8 @@ struct PyrParams {
   int enc_kp;
 };
 
+constexpr int PYR_INT_XCD_REMAP = 1 << 16;  // internal flag, set by the launcher
+
 constexpr int ENC_N = 128;       // output channels of the fused 1x1 convolution (UpdateModule.corr_encoder[0])
 constexpr int ENC_XPITCH = 200;  // halves per pixel row of the LDS operand tile: 100 dwords -> the 16 rows of a fragment
                                  // read start 36 banks apart, conflict-free
@@ -451,6 +453,13 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int bid = blockIdx.x;
+  if (p.flags & PYR_INT_XCD_REMAP) {
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Consecutive tiles share output lines
+    // (a 16-pixel tile writes half of each 128-byte row segment): give every XCD a contiguous run of tiles so that
+    // the two halves of a line meet in ONE L2 and leave it as a full-line write.
+    const int n8 = (int)(gridDim.x & ~7u);
+    if (bid < n8) bid = (bid & 7) * (n8 >> 3) + (bid >> 3);
+  }
   const int tile = bid % p.tiles_per_row;
   bid /= p.tiles_per_row;
   const int y = bid % p.H1;
@@ -789,13 +798,14 @@ static size_t pyr_lds_bytes(int L, int radius) {
 
 // KIND 0: LDS-DMA staged kernel; 1-3: register-gather kernel (4 px/wave; 2 px/wave with 16- / 32-pixel tiles);
 // 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles);
-// 6 / 7: KIND 5 with channel-last fp32 / half output (no LDS); 8: KIND 5 with the fused corr_encoder layer
+// 8: KIND 5 with the fused corr_encoder layer; 9 / 10: the tiled gather kernel with channel-last half / fp32 output
+// (no LDS, no barrier: 8-pixel tiles = 4-wave workgroups, which refill freed wave slots sooner than 16-wave ones)
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
-  constexpr int tpx = (KIND == 3 || KIND >= 5) ? 32 : TP;
+  constexpr int tpx = KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
-                     : KIND >= 6 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
+                     : KIND >= 9 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
@@ -804,10 +814,10 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   else if constexpr (KIND == 3) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, false>;
   else if constexpr (KIND == 4) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
   else if constexpr (KIND == 5) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
-  else if constexpr (KIND == 6) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 1>;
-  else if constexpr (KIND == 7) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 2>;
-  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
-  const int nthreads = (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
+  else if constexpr (KIND == 8) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
+  else if constexpr (KIND == 9) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 2>;
+  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 1>;
+  const int nthreads = KIND >= 9 ? (tpx / 2) * kWave : (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
   static bool attr_set = false;  // idempotent; racing setters write the same value
@@ -816,6 +826,7 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
     attr_set = true;
   }
   const unsigned grid = (unsigned)((size_t)q.E * q.H1 * q.tiles_per_row);
+  if (KIND == 2 || KIND == 4) q.flags |= PYR_INT_XCD_REMAP;  // 16-pixel tiles with planar output
   hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, q);
   return launch_status();
 }
@@ -906,13 +917,13 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
 #define LGU_LAUNCH_K(PR, ZM, KD)                                                                   \
   (radius == 3 ? launch_fast<3, PR, ZM, KD>(p, st)                                                 \
                : radius == 2 ? launch_fast<2, PR, ZM, KD>(p, st) : launch_fast<1, PR, ZM, KD>(p, st))
-      // production choice of tile width: 32 pixels (full 128-byte output lines, 1024-thread
-      // workgroups) unless 16-pixel tiles waste fewer lanes on this W1
-      const int slots16 = ((W1 + 15) / 16) * 16, slots32 = ((W1 + 31) / 32) * 32;
-      const bool wide = variant == 4 || (variant != 5 && slots32 <= slots16);
+      // production choice of tile width: 16 pixels (8-wave workgroups) with the XCD-aware tile order that lets the
+      // two half-line writes of neighbouring tiles merge in one L2; variant 4 = 32-pixel tiles (full-line writes
+      // from one workgroup, 16-wave workgroups), 3.5 % slower
+      const bool wide = variant == 4;
 #define LGU_LAUNCH(PR, ZM)                                                                                     \
   (enc ? launch_fast<3, PR, ZM, 8>(p, st) :                                                                    \
-   out_f16 ? launch_fast<3, PR, ZM, 7>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 6>(p, st) :                  \
+   out_f16 ? launch_fast<3, PR, ZM, 9>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 10>(p, st) :                  \
    tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
          : variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                                                              \
                         : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))

@@ -98,11 +98,16 @@ br = json.load(open(os.path.join(G, "bench_rowmajor.json")))
 bp = json.load(open(os.path.join(G, "bench_probe.json")))
 bl = json.load(open(os.path.join(G, "bench_lowmem.json")))
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
+bh = json.load(open(os.path.join(G, "bench_nhwc_f16.json"))) if os.path.exists(os.path.join(G, "bench_nhwc_f16.json")) else None
+if os.path.exists(os.path.join(G, "ab_encoder.jsonl")):
+    import shutil
+    shutil.copy(os.path.join(G, "ab_encoder.jsonl"), os.path.join(P, "%s_ab_encoder_formats.jsonl" % tag))
 keep = ("value", "ms_per_step", "roofline", "config")
 json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py (tiled pyramid), bench.py --layout rowmajor, "
                    "bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic for both layouts, low-memory kernel trace, "
                    "comparison with the reference kernels (oracle/_ref) on the same device",
            "bench": b, "bench_rowmajor": {k: br[k] for k in keep}, "bench_probe": {k: bp[k] for k in keep}, "bench_lowmem_config4": bl,
+           "bench_out_format_nhwc_f16": {k: bh[k] for k in keep} if bh else None,
            "kernel_stats_defcorr_tiled": dict(kern_t), "kernel_stats_defcorr_rowmajor": dict(kern_r),
            "traffic_tiled": traffic_t, "traffic_rowmajor": traffic_r, "lowmem_kernels": lowmem, "compare_ref": cmp_},
           open(os.path.join(P, "%s_final.json" % tag), "w"), indent=1)

@@ -19,8 +19,10 @@ cat gpurun_out/bench.json | cut -c1-1800
 timeout -k 10 300 python bench.py --no-cpu --layout rowmajor > gpurun_out/bench_rowmajor.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --workload lowmem --edges 16 > gpurun_out/bench_lowmem.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --no-cpu --probe > gpurun_out/bench_probe.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu --out-format nhwc_f16 > gpurun_out/bench_nhwc_f16.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python tools/ab_encoder.py > gpurun_out/ab_encoder.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 python -c "import json
-for n in ('bench_rowmajor','bench_probe','bench_lowmem'):
+for n in ('bench_rowmajor','bench_probe','bench_lowmem','bench_nhwc_f16'):
     d=json.load(open('gpurun_out/%s.json'%n)); print(n,'value',round(d['value'],1),'ms',round(d['ms_per_step'],4),'frac',round(d['roofline']['frac'],4))"
 rm -rf gpurun_out/prof_trace* gpurun_out/prof_fetch* gpurun_out/prof_write* gpurun_out/prof_lm
 cd /tmp
