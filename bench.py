@@ -409,8 +409,9 @@ def main():
                  3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
                  2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
         kname = kname.replace("LAYOUT", "true" if tiled else "false")
-        if args.out_format != "planar":  # channel-last forms: 8-pixel tiles
-            kname = kname.replace(",2,16,", ",2,8,")[:-1] + (",1>" if args.out_format == "nhwc" else ",2>")
+        if "gather_kernel" in kname:  # trailing template argument = output form; channel-last forms run 8-pixel tiles
+            om = {"planar": 0, "nhwc": 1, "nhwc_f16": 2}[args.out_format]
+            kname = (kname.replace(",2,16,", ",2,8,") if om else kname)[:-1] + ",%d>" % om
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
         # because counters cannot be collected from inside the timed process; see profiles/.
