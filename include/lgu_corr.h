@@ -162,6 +162,12 @@ int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* v
 int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const float* volume, float* const* levels,
                                  int L, int E, int H1, int W1, int H2, int W2, int radius, void* stream);
 
+/* The same over a HALF raw volume (what the all-pairs product of the half feature maps returns, corr.py:145-152): the
+ * `.float()` of corr.py:64 becomes this kernel's load (exact) instead of a pass of its own over the volume.  Levels are
+ * fp32 as above; tiled != 0 writes them in the tiled slice layout.  levels[0] cannot alias `volume`. */
+int lgu_volume_pyramid_h16(const float* means, const float* covs, const void* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int radius, int tiled, void* stream);
+
 /* Layout conversion of `nslices` slices of H2 x W2 floats: to_tiled != 0: row-major -> tiled, else tiled -> row-major
  * (padding elements of the tiled form are written as 0).  src and dst must not overlap. */
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream);

@@ -27,6 +27,7 @@ SIGNATURES = {
                                           ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _vp],
     "lgu_volume_pyramid_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_pyramid_tiled_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
+    "lgu_volume_pyramid_h16": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_retile_f32": [_vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp],
     "lgu_lowmem_defsample_fwd_f32": [_vp] * 5 + [_int] * 9 + [_vp],
     "lgu_altcorr_fwd_f32": [_vp] * 4 + [_int] * 8 + [_vp],

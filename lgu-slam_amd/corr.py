@@ -118,7 +118,8 @@ class CorrBlock:
         self.ofs_residual = ofs_residual
 
         b, n, ch, h, w = fmap1.shape
-        volume = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w).float()
+        raw = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w)  # half when the feature maps are (depth_video's)
+        volume = None                                               # raw.float() (corr.py:64), made only where needed
         feats = torch.cat((fmap1.reshape(b * n, ch, h, w), fmap2.reshape(b * n, ch, h, w)), dim=1)
         self.t = feats
         self.offset, self._zero_level = generate_offsets(ofsMap, ofs_residual, feats, num_levels)
@@ -135,13 +136,15 @@ class CorrBlock:
             mean_n, cov, det = GA.gaussian_parameters(self.t)
             tiled = bool(CorrBlock.TILED_PYRAMID) and radius == 3
             try:
-                self._adopt_store(ops.volume_pyramid(mean_n.float().contiguous(), cov, volume.contiguous(), num_levels,
+                # a half raw volume is converted by the builder's own load, not by a .float() pass
+                src = raw.contiguous() if raw.dtype == torch.float16 else raw.float().contiguous()
+                self._adopt_store(ops.volume_pyramid(mean_n.float().contiguous(), cov.float().contiguous(), src, num_levels,
                                                      GA.RADIUS, inplace=True, tiled=tiled))
                 self._tiled = tiled
             except _lib.UnsupportedShape:
                 self.corr_pyramid = None
         if self._store is None and self._pyr is None:
-            volume, mean_n, det = GA(self.t, volume)
+            volume, mean_n, det = GA(self.t, raw.float())
             # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
             self.corr_pyramid = []
             lvl = volume.reshape(b * n * h * w, 1, h, w)

@@ -148,8 +148,8 @@ constexpr int VP_MAXL = 4;
 struct VolPyrParams {
   const float* means;
   const float* covs;
-  const float* vin;
-  float* out[VP_MAXL];  // out[0] may alias vin
+  const void* vin;      // fp32, or half when the kernel's HALF_IN is set
+  float* out[VP_MAXL];  // out[0] may alias an fp32 vin
   size_t npix;
   int H2, W2, L, r;
 };
@@ -161,7 +161,9 @@ __device__ __forceinline__ int tiled_pos(int y, int x, int tpr) {
   return (((y >> 2) * tpr + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
 }
 
-template <bool TILED>
+// HALF_IN: the raw volume is IEEE half — what the all-pairs matmul of half feature maps returns (corr.py:145-152 on
+// depth_video's half fmaps); the `.float()` of corr.py:64 is then this kernel's load (exact), not a 1.1 GB pass of its own.
+template <bool TILED, bool HALF_IN>
 __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyrParams p) {
   extern __shared__ float4 vp_smem4[];
   float* const sm = reinterpret_cast<float*>(vp_smem4);
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
   const float den = 6.28f * sqrtf(c1 * c2);  // gaussianMask_cuda.py:79,85 (det = cov0*cov1)
   const int cx = (int)floorf(mx), cy = (int)floorf(my);
   const int xa = cx - p.r, xb = cx + p.r, ya = cy - p.r, yb = cy + p.r;
-  const float4* vin = reinterpret_cast<const float4*>(p.vin + pix * (size_t)HW2);
+  typedef _Float16 vp_half4 __attribute__((ext_vector_type(4)));
+  const float4* vin = reinterpret_cast<const float4*>(static_cast<const float*>(p.vin) + (HALF_IN ? 0 : pix * (size_t)HW2));
+  const vp_half4* vinh = reinterpret_cast<const vp_half4*>(static_cast<const _Float16*>(p.vin) + (HALF_IN ? pix * (size_t)HW2 : 0));
   const int tpr0 = (W2 + 7) >> 3;
   const int ssz0 = TILED ? ((H2 + 3) >> 2) * tpr0 * 32 : HW2;
   float4* vout = reinterpret_cast<float4*>(p.out[0] + pix * (size_t)ssz0);
@@ -180,7 +184,13 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
   for (int gi = threadIdx.x; gi < (HW2 >> 2); gi += VP_THREADS) {
     const int row = gi / g_per_row;
     const int x4 = (gi - row * g_per_row) << 2;
-    float4 v = vin[gi];
+    float4 v;
+    if constexpr (HALF_IN) {
+      const vp_half4 hv = vinh[gi];
+      v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+    } else {
+      v = vin[gi];
+    }
     if (row >= ya && row <= yb && x4 + 3 >= xa && x4 <= xb) {
       // inside the window: corr1 / denominator + corr; outside corr1 == 0 and the sum is v exactly
       if (x4 + 0 >= xa && x4 + 0 <= xb) v.x = (v.x * 3.0f * gauss_e(x4 + 0, row, mx, my, c1, c2)) / den + v.x;
@@ -302,8 +312,9 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
   return launch_status();
 }
 
-static int volume_pyramid_host(const float* means, const float* covs, const float* volume, float* const* levels, int L,
-                               int E, int H1, int W1, int H2, int W2, int radius, bool tiled, void* stream) {
+static int volume_pyramid_host(const float* means, const float* covs, const void* volume, float* const* levels, int L,
+                               int E, int H1, int W1, int H2, int W2, int radius, bool tiled, void* stream,
+                               bool half_in = false) {
   using namespace lgu;
   if (!means || !covs || !volume || !levels || L < 1 || L > VP_MAXL) return LGU_E_BADARG;
   if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
@@ -312,6 +323,7 @@ static int volume_pyramid_host(const float* means, const float* covs, const floa
   if (W2 % 4 != 0 || ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(levels[0])) & 15) != 0)
     return LGU_E_UNSUPPORTED;
   if (tiled && levels[0] == volume && (H2 % 4 != 0 || W2 % 8 != 0)) return LGU_E_BADARG;  // padded slice cannot alias
+  if (half_in && static_cast<const void*>(levels[0]) == volume) return LGU_E_BADARG;        // nor can a half volume
   size_t floats = 0;
   for (int l = 0, h = H2, w = W2; l < L; l++, h >>= 1, w >>= 1) floats += (size_t)h * w;
   const size_t lds = floats * sizeof(float);
@@ -321,11 +333,12 @@ static int volume_pyramid_host(const float* means, const float* covs, const floa
   p.means = means; p.covs = covs; p.vin = volume;
   for (int l = 0; l < VP_MAXL; l++) p.out[l] = l < L ? levels[l] : nullptr;
   p.npix = (size_t)E * H1 * W1; p.H2 = H2; p.W2 = W2; p.L = L; p.r = radius;
-  auto kern = tiled ? volume_pyramid_kernel<true> : volume_pyramid_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[tiled]) {
+  auto kern = half_in ? (tiled ? volume_pyramid_kernel<true, true> : volume_pyramid_kernel<false, true>)
+                      : (tiled ? volume_pyramid_kernel<true, false> : volume_pyramid_kernel<false, false>);
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[tiled + 2 * half_in]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[tiled] = true;
+    attr_set[tiled + 2 * half_in] = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)p.npix), dim3(VP_THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
   return launch_status();
@@ -339,6 +352,11 @@ int lgu_volume_pyramid_f32(const float* means, const float* covs, const float* v
 int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const float* volume, float* const* levels,
                                  int L, int E, int H1, int W1, int H2, int W2, int radius, void* stream) {
   return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, true, stream);
+}
+
+int lgu_volume_pyramid_h16(const float* means, const float* covs, const void* volume, float* const* levels, int L,
+                           int E, int H1, int W1, int H2, int W2, int radius, int tiled, void* stream) {
+  return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, tiled != 0, stream, true);
 }
 
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream) {

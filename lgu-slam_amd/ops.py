@@ -403,25 +403,39 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     + corr.py:79-86): level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(det)) +
     volume, levels 1.. by 2x2 average pooling of the target dims — one pass over the volume.
     Returns the list of pyramid levels; with inplace=True level 0 reuses `volume`'s storage.
-    tiled=True: the levels are written in the tiled slice layout (tiled_shape); same values."""
-    _check(volume, "volume", means, "means", covs, "covs")
+    tiled=True: the levels are written in the tiled slice layout (tiled_shape); same values.
+    A HALF volume (the matmul of half feature maps) is converted by the kernel's own load — the levels are fp32 and
+    equal those of volume.float(); inplace is then ignored."""
+    half_in = volume.dtype == torch.float16
+    if half_in:
+        _check(means, "means", covs, "covs")
+        if not (volume.is_cuda and volume.is_contiguous()):
+            raise RuntimeError("volume must be a contiguous CUDA tensor")
+        inplace = False
+    else:
+        _check(volume, "volume", means, "means", covs, "covs")
     E, H1, W1, H2, W2 = volume.shape
+    f32 = torch.float32
     if tiled:
         alias = inplace and H2 % TILE_H == 0 and W2 % TILE_W == 0
         levels = [volume.view(tiled_shape(E, H1, W1, H2, W2)) if alias
-                  else torch.empty(tiled_shape(E, H1, W1, H2, W2), dtype=volume.dtype, device=volume.device)]
+                  else torch.empty(tiled_shape(E, H1, W1, H2, W2), dtype=f32, device=volume.device)]
         for l in range(1, num_levels):
-            levels.append(torch.empty(tiled_shape(E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+            levels.append(torch.empty(tiled_shape(E, H1, W1, H2 >> l, W2 >> l), dtype=f32, device=volume.device))
     else:
-        levels = [volume if inplace else torch.empty_like(volume)]
+        levels = [volume if inplace else torch.empty(volume.shape, dtype=f32, device=volume.device)]
         for l in range(1, num_levels):
-            levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=volume.dtype, device=volume.device))
+            levels.append(torch.empty((E, H1, W1, H2 >> l, W2 >> l), dtype=f32, device=volume.device))
     if E == 0:
         return levels
     lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
-    fn = _lib.load().lgu_volume_pyramid_tiled_f32 if tiled else _lib.load().lgu_volume_pyramid_f32
     with torch.cuda.device(volume.device):
-        rc = fn(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2, W2, radius, _stream(volume))
+        if half_in:
+            rc = _lib.load().lgu_volume_pyramid_h16(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2, W2,
+                                                    radius, 1 if tiled else 0, _stream(volume))
+        else:
+            fn = _lib.load().lgu_volume_pyramid_tiled_f32 if tiled else _lib.load().lgu_volume_pyramid_f32
+            rc = fn(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2, W2, radius, _stream(volume))
     _lib.check(rc, "volume_pyramid")
     return levels
 

@@ -783,6 +783,24 @@ def test_channel_last_output_argument_checks(lgu):
     assert rc == lgu._lib.LGU_E_BADARG
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("shape,L", [((2, 12, 16, 12, 16), 3), ((1, 24, 32, 24, 32), 4), ((2, 6, 8, 20, 24), 2)])
+def test_volume_pyramid_half_input_is_the_float_input(lgu, shape, L, tiled):
+    """lgu_volume_pyramid_h16: the raw volume handed over in half (the matmul of half feature maps) gives BIT FOR BIT
+    the levels of volume.float() (the conversion is exact and happens in the kernel's load); never in place."""
+    torch.manual_seed(sum(shape) + L)
+    E, H1, W1, H2, W2 = shape
+    vol16 = (torch.randn(*shape, device="cuda") * 0.3).half()
+    means = torch.stack([torch.rand(E, H1, W1, device="cuda") * W2, torch.rand(E, H1, W1, device="cuda") * H2], -1).contiguous()
+    covs = (torch.rand(E, H1, W1, 2, device="cuda") * 5 + 0.05).contiguous()
+    keep = vol16.clone()
+    got = lgu.ops.volume_pyramid(means, covs, vol16, L, 4, inplace=True, tiled=tiled)
+    want = lgu.ops.volume_pyramid(means, covs, vol16.float(), L, 4, tiled=tiled)
+    assert torch.equal(vol16, keep)
+    for g, w_ in zip(got, want):
+        assert g.dtype == torch.float32 and torch.equal(g, w_)
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]
