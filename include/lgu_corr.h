@@ -147,6 +147,19 @@ int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge
                                     int L, int E, int H1, int W1, const int* H2, const int* W2,
                                     int radius, int enc_n, int flags, void* stream);
 
+/* Post-processing of the learned sampling offsets (reference droid_slam/modules/corr.py:117-135 and :217-235 with
+ * per_Corr_Normalization, gaussianMask_cuda.py:26-33) in one pass:
+ *   o0 (E,C,H,W), o1 (E,C,Hl,Wl): the outputs of the two offset convolutions (o1 still at the pooled resolution; the
+ *   nearest-neighbour upsampling to (H,W) is an index map inside the kernel), fp32 or IEEE half (is_half);
+ *   out0 = 4 tanh((o0 - mean) / sqrt(var + eps)),  out1 = (4 tanh((o1 - mean1) / sqrt(var1 + eps)) + out0) / 2,
+ *   statistics per edge over (C,H,W), biased variance; both written as (E,H,W,C) fp32 — the (E,H,W,rd,rd,2) tensors
+ *   the samplers take.  is_half = 1: every step is rounded to half as the framework's half kernels do; is_half = 2: the
+ *   same for level 0, level 1 in fp32 — what autocast yields, which promotes the nearest upsampling to fp32.
+ * scratch: lgu_offsets_finalize_scratch_bytes(E) bytes of device memory (partial sums; no initialisation needed). */
+long long lgu_offsets_finalize_scratch_bytes(int E);
+int lgu_offsets_finalize(const void* o0, const void* o1, float* out0, float* out1, void* scratch,
+                         int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps, void* stream);
+
 /* Fused volume post-processing of CorrBlock.__init__ (reference droid_slam/gaussianMask_cuda.py:84-86
  * and droid_slam/modules/corr.py:79-86): in ONE pass over the raw all-pairs volume
  *   level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(covs.x*covs.y)) + volume

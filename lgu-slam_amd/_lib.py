@@ -28,6 +28,7 @@ SIGNATURES = {
     "lgu_volume_pyramid_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_pyramid_tiled_f32": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_pyramid_h16": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _int, _vp],
+    "lgu_offsets_finalize": [_vp] * 5 + [_int] * 7 + [ctypes.c_float, _vp],
     "lgu_volume_retile_f32": [_vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp],
     "lgu_lowmem_defsample_fwd_f32": [_vp] * 5 + [_int] * 9 + [_vp],
     "lgu_altcorr_fwd_f32": [_vp] * 4 + [_int] * 8 + [_vp],
@@ -90,6 +91,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, let it surface
         fn.argtypes = argtypes
         fn.restype = _int
+    lib.lgu_offsets_finalize_scratch_bytes.restype = ctypes.c_longlong
+    lib.lgu_offsets_finalize_scratch_bytes.argtypes = [_int]
     lib.lgu_version.restype = ctypes.c_char_p
     lib.lgu_error_string.restype = ctypes.c_char_p
     lib.lgu_error_string.argtypes = [_int]

@@ -60,6 +60,9 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
     return (x - mean) / std
 
 
+FUSED_OFFSETS = True   # False: the reference-shaped torch composition below also in inference (A/B and tests)
+
+
 def generate_offsets(ofsMap, ofs_residual, feats, num_levels):
     """Learned sampling offsets (reference corr.py:117-135 / :217-235).
 
@@ -70,7 +73,23 @@ def generate_offsets(ofsMap, ofs_residual, feats, num_levels):
     """
     _, _, h, w = feats.shape
     o0 = ofsMap(feats)
-    o1 = F.interpolate(ofs_residual(F.avg_pool2d(feats, kernel_size=2, stride=2)), (h, w))
+    o1_low = ofs_residual(F.avg_pool2d(feats, kernel_size=2, stride=2))
+    return finish_offsets(o0, o1_low, num_levels)
+
+
+def finish_offsets(o0, o1_low, num_levels):
+    """Everything of generate_offsets after the two convolutions: o0 (E,C,h,w), o1_low (E,C,h/2,w/2)."""
+    h, w = o0.shape[2:]
+    if (FUSED_OFFSETS and num_levels >= 2 and o0.is_cuda and not (torch.is_grad_enabled() and o0.requires_grad)
+            and o0.dtype in (torch.float32, torch.float16) and o1_low.dtype == o0.dtype):
+        # inference: standardisation, tanh, residual mix, upsampling and the channel-last transposition in one pass
+        try:
+            off0, off1 = ops.offsets_finalize(o0.contiguous(), o1_low.contiguous())
+            offsets = [off0, off1] + [torch.zeros_like(off0) for _ in range(2, num_levels)]
+            return offsets[:num_levels], ([False, False] + [True] * (num_levels - 2))[:num_levels]
+        except _lib.UnsupportedShape:
+            pass
+    o1 = F.interpolate(o1_low, (h, w))
     o0 = torch.tanh(per_Corr_Normalization(o0, [1, 2, 3])) * 4
     o1 = (torch.tanh(per_Corr_Normalization(o1, [1, 2, 3])) * 4 + o0) / 2
     offsets = [o0.permute(0, 2, 3, 1), o1.permute(0, 2, 3, 1)]

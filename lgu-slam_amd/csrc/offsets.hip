@@ -1,0 +1,186 @@
+// offsets.hip — post-processing of the learned sampling offsets in one pass (gfx950).
+//
+// Reference composition (droid_slam/modules/corr.py:117-135 for CorrBlock, :217-235 for AltCorrBlock, with
+// per_Corr_Normalization of gaussianMask_cuda.py:26-33), per new edge set:
+//     o0 = ofsMap(feats)                                        (E,C,h,w)   C = 2*rd*rd
+//     o1 = interpolate(ofs_residual(avg_pool2d(feats, 2)), (h,w))           nearest
+//     o0 = 4 * tanh((o0 - mean(o0)) / sqrt(var(o0) + eps))      statistics per sample over (C,h,w), biased variance
+//     o1 = (4 * tanh((o1 - mean(o1)) / sqrt(var(o1) + eps)) + o0) / 2
+//     offset[l] = o_l.permute(0,2,3,1) ... .float().contiguous()            what the samplers take: (E,h,w,rd,rd,2)
+// = 4 reductions with one output per sample (latency-bound: ~40 us each at 20 edges), ~14 elementwise passes and two
+// transposing copies.  Here: one statistics kernel (fp64 partial sums per chunk, no atomics: deterministic) and one
+// finalize kernel that reads the two convolution outputs once (the low-resolution one through the nearest-neighbour
+// index map, never materialising the upsampled tensor) and writes both offset tensors channel-last in fp32.
+//
+// Arithmetic mirrors the torch ops.  fp32 inputs: the same fp32 operations in the same order (x - m) / s, tanhf, * 4,
+// (+ o0) / 2.  Half inputs (the convolutions run under autocast in factor_graph.add_factors): torch evaluates every op
+// in fp32 and rounds its result to half, so each step below is rounded to half as well; autocast promotes the nearest
+// upsampling to fp32, so there (is_half == 2) level 1 is fp32 arithmetic on the half-valued inputs plus the half-rounded
+// level 0.  The statistics differ from torch's in summation order only (fp64 sums here).
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+constexpr int OF_CHUNKS = 64;    // partial sums per sample
+constexpr int OF_THREADS = 256;
+constexpr int OF_TP = 32;        // pixels per workgroup of the finalize kernel
+
+struct OffParams {
+  const void* o0;   // (E,C,H,W)
+  const void* o1;   // (E,C,Hl,Wl)
+  float* out0;      // (E,H,W,C)
+  float* out1;
+  double* partial;  // (E, OF_CHUNKS, 4): sum0, sumsq0, sum1, sumsq1
+  int E, C, H, W, Hl, Wl;
+  float sy, sx;     // Hl / H, Wl / W as torch's nearest interpolate forms them
+  float eps;
+  int l1_f32;       // half inputs under autocast: the upsampling is promoted to fp32 there, so level 1 is fp32 arithmetic
+};
+
+template <bool HALF>
+__device__ __forceinline__ float of_load(const void* base, size_t i) {
+  if (HALF) return (float)static_cast<const _Float16*>(base)[i];
+  return static_cast<const float*>(base)[i];
+}
+
+// nearest-neighbour source index (ATen upsample_nearest: min(floor(dst * scale), in - 1))
+__device__ __forceinline__ int of_src(int dst, float scale, int in) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+__device__ __forceinline__ float of_rh(float v) { return (float)(_Float16)v; }  // round to half, back to float
+
+template <bool HALF>
+__global__ __launch_bounds__(OF_THREADS) void offsets_stats_kernel(const OffParams p) {
+  const int e = blockIdx.y, chunk = blockIdx.x;
+  const int HW = p.H * p.W;
+  const size_t n = (size_t)p.C * HW;
+  const size_t per = (n + OF_CHUNKS - 1) / OF_CHUNKS;
+  const size_t lo = (size_t)chunk * per, hi = lo + per < n ? lo + per : n;
+  const size_t b0 = (size_t)e * n, b1 = (size_t)e * p.C * p.Hl * p.Wl;
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += OF_THREADS) {
+    const int c = (int)(i / HW), r = (int)(i - (size_t)c * HW);
+    const int y = r / p.W, x = r - y * p.W;
+    const double a = of_load<HALF>(p.o0, b0 + i);
+    const double b = of_load<HALF>(p.o1, b1 + ((size_t)c * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
+    s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+  }
+  __shared__ double red[OF_THREADS / kWave][4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    s0 += __shfl_xor(s0, m, kWave); q0 += __shfl_xor(q0, m, kWave);
+    s1 += __shfl_xor(s1, m, kWave); q1 += __shfl_xor(q1, m, kWave);
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv][0] = s0; red[wv][1] = q0; red[wv][2] = s1; red[wv][3] = q1; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0.0;
+    for (int k = 0; k < OF_THREADS / kWave; k++) t += red[k][threadIdx.x];
+    p.partial[((size_t)e * OF_CHUNKS + chunk) * 4 + threadIdx.x] = t;
+  }
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffParams p) {
+  extern __shared__ float of_sm[];  // [2][C][OF_TP + 1]
+  __shared__ float stat[4];          // mean0, std0, mean1, std1
+  const int e = blockIdx.y;
+  const int HW = p.H * p.W, C = p.C;
+  const int pix0 = blockIdx.x * OF_TP;
+  if (threadIdx.x < 2) {  // fixed-order sum of the partials: deterministic
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < OF_CHUNKS; k++) {
+      s += p.partial[((size_t)e * OF_CHUNKS + k) * 4 + threadIdx.x * 2 + 0];
+      q += p.partial[((size_t)e * OF_CHUNKS + k) * 4 + threadIdx.x * 2 + 1];
+    }
+    const double n = (double)C * HW;
+    const double mean = s / n;
+    double var = q / n - mean * mean;  // biased (unbiased=False)
+    var = var > 0.0 ? var : 0.0;
+    float m = (float)mean, sd;
+    if (HALF && !(p.l1_f32 && threadIdx.x == 1)) {  // torch: mean / var come back as half tensors; var + eps and sqrt are half ops
+      m = of_rh(m);
+      sd = of_rh(sqrtf(of_rh(of_rh((float)var) + p.eps)));
+    } else {
+      sd = sqrtf((float)var + p.eps);
+    }
+    stat[threadIdx.x * 2 + 0] = m;
+    stat[threadIdx.x * 2 + 1] = sd;
+  }
+  __syncthreads();
+  const float m0 = stat[0], sd0 = stat[1], m1 = stat[2], sd1 = stat[3];
+  float* const t0 = of_sm;
+  float* const t1 = of_sm + (size_t)C * (OF_TP + 1);
+  const size_t b0 = (size_t)e * C * HW, b1 = (size_t)e * C * p.Hl * p.Wl;
+  for (int idx = threadIdx.x; idx < C * OF_TP; idx += OF_THREADS) {
+    const int c = idx / OF_TP, pp = idx - c * OF_TP;
+    const int pix = pix0 + pp;
+    if (pix >= HW) continue;
+    const int y = pix / p.W, x = pix - y * p.W;
+    const float a = of_load<HALF>(p.o0, b0 + (size_t)c * HW + pix);
+    const float b = of_load<HALF>(p.o1, b1 + ((size_t)c * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
+    float v0, v1;
+    if (HALF) {
+      v0 = of_rh(of_rh(tanhf(of_rh(of_rh(a - m0) / sd0))) * 4.0f);
+      if (p.l1_f32) {
+        v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
+      } else {
+        const float u = of_rh(of_rh(tanhf(of_rh(of_rh(b - m1) / sd1))) * 4.0f);
+        v1 = of_rh(of_rh(u + v0) / 2.0f);
+      }
+    } else {
+      v0 = tanhf((a - m0) / sd0) * 4.0f;
+      v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
+    }
+    t0[c * (OF_TP + 1) + pp] = v0;
+    t1[c * (OF_TP + 1) + pp] = v1;
+  }
+  __syncthreads();
+  const int npx = HW - pix0 < OF_TP ? HW - pix0 : OF_TP;
+  float* const d0 = p.out0 + ((size_t)e * HW + pix0) * C;
+  float* const d1 = p.out1 + ((size_t)e * HW + pix0) * C;
+  for (int idx = threadIdx.x; idx < npx * C; idx += OF_THREADS) {  // channel-last rows: one contiguous run per tile
+    const int pp = idx / C, c = idx - pp * C;
+    d0[idx] = t0[c * (OF_TP + 1) + pp];
+    d1[idx] = t1[c * (OF_TP + 1) + pp];
+  }
+}
+
+}  // namespace lgu
+
+extern "C" {
+
+long long lgu_offsets_finalize_scratch_bytes(int E) {
+  return E < 0 ? 0 : (long long)E * lgu::OF_CHUNKS * 4 * (long long)sizeof(double);
+}
+
+int lgu_offsets_finalize(const void* o0, const void* o1, float* out0, float* out1, void* scratch, int E, int C, int H,
+                         int W, int Hl, int Wl, int is_half, float eps, void* stream) {
+  using namespace lgu;
+  if (!o0 || !o1 || !out0 || !out1 || !scratch) return LGU_E_BADARG;
+  if (E < 0 || C < 1 || H < 1 || W < 1 || Hl < 1 || Wl < 1) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  const size_t lds = sizeof(float) * 2 * (size_t)C * (OF_TP + 1);
+  if (lds > 60 * 1024 || E > 65535) return LGU_E_UNSUPPORTED;
+  OffParams p;
+  p.o0 = o0; p.o1 = o1; p.out0 = out0; p.out1 = out1; p.partial = static_cast<double*>(scratch);
+  p.E = E; p.C = C; p.H = H; p.W = W; p.Hl = Hl; p.Wl = Wl;
+  p.sy = (float)Hl / (float)H; p.sx = (float)Wl / (float)W;
+  p.eps = eps;
+  p.l1_f32 = is_half == 2;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g1(OF_CHUNKS, E), g2((H * W + OF_TP - 1) / OF_TP, E);
+  if (is_half) {
+    hipLaunchKernelGGL(offsets_stats_kernel<true>, g1, dim3(OF_THREADS), 0, st, p);
+    hipLaunchKernelGGL(offsets_finalize_kernel<true>, g2, dim3(OF_THREADS), lds, st, p);
+  } else {
+    hipLaunchKernelGGL(offsets_stats_kernel<false>, g1, dim3(OF_THREADS), 0, st, p);
+    hipLaunchKernelGGL(offsets_finalize_kernel<false>, g2, dim3(OF_THREADS), lds, st, p);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

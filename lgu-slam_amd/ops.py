@@ -440,6 +440,37 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+def offsets_finalize(o0, o1_lowres, eps=1e-5, autocast=None):
+    """Post-processing of the two offset convolutions' outputs (reference corr.py:117-135 / :217-235) in one pass:
+    per-sample standardisation, 4*tanh, the level-1 residual mix, nearest upsampling of the pooled-resolution head and
+    the transposition to the samplers' channel-last fp32 layout.  o0 (E,C,H,W), o1_lowres (E,C,Hl,Wl), both fp32 or
+    both half.  Half inputs: every step rounded to half like torch's half kernels; with autocast (default: whether
+    autocast is enabled now) level 1 is evaluated in fp32, because autocast promotes the nearest upsampling to fp32.
+    Returns (off0, off1), each (E,H,W,C) fp32."""
+    if autocast is None:
+        autocast = torch.is_autocast_enabled()
+    if o0.dtype not in (torch.float32, torch.float16) or o1_lowres.dtype != o0.dtype:
+        raise RuntimeError("offsets_finalize: fp32 or half inputs of one dtype")
+    for t, n in ((o0, "o0"), (o1_lowres, "o1")):
+        if not (t.is_cuda and t.is_contiguous() and t.dim() == 4):
+            raise RuntimeError("%s must be a contiguous 4-d CUDA tensor" % n)
+    E, C, H, W = o0.shape
+    if o1_lowres.shape[:2] != (E, C):
+        raise RuntimeError("offsets_finalize: o1 must have o0's (E, C)")
+    Hl, Wl = o1_lowres.shape[2:]
+    out0 = torch.empty((E, H, W, C), dtype=torch.float32, device=o0.device)
+    out1 = torch.empty_like(out0)
+    if E == 0:
+        return out0, out1
+    lib = _lib.load()
+    scratch = torch.empty(int(lib.lgu_offsets_finalize_scratch_bytes(E)), dtype=torch.uint8, device=o0.device)
+    with torch.cuda.device(o0.device):
+        rc = lib.lgu_offsets_finalize(_ptr(o0), _ptr(o1_lowres), _ptr(out0), _ptr(out1), _ptr(scratch), E, C, H, W, Hl, Wl,
+                                      (2 if autocast else 1) if o0.dtype == torch.float16 else 0, float(eps), _stream(o0))
+    _lib.check(rc, "offsets_finalize")
+    return out0, out1
+
+
 ENC_N = 128  # output channels of the fused corr_encoder layer (csrc/defcorr.hip)
 
 

@@ -801,6 +801,47 @@ def test_volume_pyramid_half_input_is_the_float_input(lgu, shape, L, tiled):
         assert g.dtype == torch.float32 and torch.equal(g, w_)
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 25, 37), (1, 48, 64)])
+def test_fused_offset_post_processing_equals_the_torch_composition(lgu, shape, half, monkeypatch):
+    """lgu_offsets_finalize (standardise + 4 tanh + residual mix + nearest upsampling + channel-last transposition in
+    one pass) against the reference-shaped torch composition of corr.py:117-135 on the SAME convolution outputs (two
+    runs of a half convolution may pick different algorithms and differ by an ulp, which the 4 tanh(x / std) amplifies).
+    fp32: the same fp32 operations, the statistics differ in summation order only (<= 1e-5 on values in [-4, 4]).
+    Half (autocast, as add_factors runs it): level 0 rounded to half at every step like the framework's half kernels,
+    level 1 in fp32 (autocast promotes the nearest upsampling) — equal bit for bit unless a statistic lands on the
+    other side of a half rounding boundary (max <= 2^-7, mean <= 1e-4 then).
+    Odd sizes exercise the nearest-neighbour index map."""
+    import lgu_slam_amd.corr as corr_mod
+    E, h, w = shape
+    torch.manual_seed(h * w + E)
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    feats = torch.randn(E, 256, h, w, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=half):
+        o0 = ofsMap(feats)
+        o1_low = ofsRes(torch.nn.functional.avg_pool2d(feats, kernel_size=2, stride=2))
+        assert o0.dtype == (torch.float16 if half else torch.float32)
+        monkeypatch.setattr(corr_mod, "FUSED_OFFSETS", True)
+        got, zg = corr_mod.finish_offsets(o0, o1_low, 4)
+        monkeypatch.setattr(corr_mod, "FUSED_OFFSETS", False)
+        want, zw = corr_mod.finish_offsets(o0, o1_low, 4)
+        full, _ = corr_mod.generate_offsets(ofsMap, ofsRes, feats, 4)   # the public entry takes the same route
+        assert tuple(full[1].shape) == (E, h, w, 98)
+    assert zg == zw == [False, False, True, True] and len(got) == 4
+    for l in range(4):
+        assert tuple(got[l].shape) == (E, h, w, 98) == tuple(want[l].shape)
+    assert got[0].dtype == torch.float32 and got[0].is_contiguous() and got[1].is_contiguous()
+    assert float(got[2].abs().max()) == 0.0 and float(got[3].abs().max()) == 0.0
+    for l in range(2):
+        d = (got[l] - want[l].float()).abs()
+        if half:
+            assert float(d.max()) <= 2.0 ** -7 and float(d.mean()) <= 1e-4, (l, float(d.max()), float(d.mean()))
+        else:
+            assert float(d.max()) <= 1e-5, (l, float(d.max()))
+        assert float(want[l].float().abs().max()) > 1.0
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]

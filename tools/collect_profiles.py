@@ -99,9 +99,11 @@ bp = json.load(open(os.path.join(G, "bench_probe.json")))
 bl = json.load(open(os.path.join(G, "bench_lowmem.json")))
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
 bh = json.load(open(os.path.join(G, "bench_nhwc_f16.json"))) if os.path.exists(os.path.join(G, "bench_nhwc_f16.json")) else None
-if os.path.exists(os.path.join(G, "ab_encoder.jsonl")):
-    import shutil
-    shutil.copy(os.path.join(G, "ab_encoder.jsonl"), os.path.join(P, "%s_ab_encoder_formats.jsonl" % tag))
+import shutil
+for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_calls.json", "%s_e2e_glue_calls.json"),
+                 ("prof_init.txt", "%s_corrblock_init.txt")):
+    if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 0:
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst % tag))
 keep = ("value", "ms_per_step", "roofline", "config")
 json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py (tiled pyramid), bench.py --layout rowmajor, "
                    "bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic for both layouts, low-memory kernel trace, "

@@ -20,6 +20,9 @@ timeout -k 10 300 python bench.py --no-cpu --layout rowmajor > gpurun_out/bench_
 timeout -k 10 300 python bench.py --workload lowmem --edges 16 > gpurun_out/bench_lowmem.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --no-cpu --probe > gpurun_out/bench_probe.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --no-cpu --out-format nhwc_f16 > gpurun_out/bench_nhwc_f16.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python tools/e2e_calls.py > gpurun_out/e2e_calls.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+{ timeout -k 10 200 python tools/prof_init.py 20 f32 && timeout -k 10 200 python tools/prof_init.py 20 half; } 2> gpurun_out/bench.err | grep "CorrBlock.__init__" > gpurun_out/prof_init.txt || { tail -5 gpurun_out/bench.err; exit 1; }
+cat gpurun_out/prof_init.txt
 timeout -k 10 300 python tools/ab_encoder.py > gpurun_out/ab_encoder.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 python -c "import json
 for n in ('bench_rowmajor','bench_probe','bench_lowmem','bench_nhwc_f16'):
