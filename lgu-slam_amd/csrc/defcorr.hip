@@ -16,11 +16,14 @@
 //     * zero-offset levels: LANES = LATTICE POINTS — all taps share one fractional part and
 //       sit on a (2r+2)^2 integer lattice = one wave; one 4-byte load per lane, taps pull
 //       their corners with ds_bpermute;
-//   a workgroup covers 32 (or 16) x-adjacent pixels, issues every load of its jobs before
+//   a workgroup covers 16 x-adjacent pixels (tiles dealt to the XCDs in contiguous runs so that the
+//   half-line writes of neighbours merge in one L2), issues every load of its jobs before
 //   the first is consumed, blends in the reference's fp32 order, parks results in an LDS
-//   transpose tile [channel][pixel] and writes full 128-byte rows straight into the
+//   transpose tile [channel][pixel] and writes 64-byte row segments straight into the
 //   concatenated (E, L*rd*rd, H1, W1) tensor.  The uncertainty probe of corr.py:94-99 is
-//   optionally fused.  Kernels in this file:
+//   optionally fused.  Other output forms (OUTM): channel-last fp32 / half rows stored from the
+//   registers, or the first corr_encoder layer applied on the matrix cores (droid_net.py:76-77).
+//   Kernels in this file:
 //     defcorr_gather_kernel   production (register gather)                  [variant 0/3/4/5]
 //     defcorr_pyr_kernel      LDS-DMA staged variant: tap box by packed DPP reduction,
 //                             global_load_lds_dwordx4 into an LDS pool — same HBM bytes,
@@ -855,10 +858,10 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production (register-gather kernel, 2 px/wave, 32- or
-  // 16-pixel tiles by W1), 4 / 5 = force 32- / 16-pixel tiles, 3 = 4 px/wave with 16-pixel tiles,
-  // 1 = LDS-DMA staged kernel, 2 = generic
-  // one-thread-per-output kernel (independent cross-check)
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production (register-gather kernel, 2 px/wave, 16-pixel tiles in
+  // XCD-aware order; 8-pixel tiles for the channel-last output forms), 4 = 32-pixel tiles, 5 = 16-pixel tiles (= 0),
+  // 3 = 4 px/wave with 16-pixel tiles, 1 = LDS-DMA staged kernel, 2 = generic one-thread-per-output kernel
+  // (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
 
   int l0 = 0;
