@@ -1196,6 +1196,24 @@ def test_randomized_differential_pyramid(lgu, seed):
     o_r = fresh()
     got_r = lgu.ops.defcorr_pyramid_forward(vols, coords, o_r, 3)
     assert torch.equal(got_r, want)
+    # the other output forms of the tiled kernel: channel-last fp32 / half, and the fused first encoder layer
+    tv = [lgu.ops.volume_retile(v) for v in vols]
+    assert torch.equal(lgu.ops.defcorr_pyramid_forward(tv, coords, fresh(), 3, tiled=True, level_hw=hw, out_format="nhwc"), want)
+    x16 = lgu.ops.defcorr_pyramid_forward(tv, coords, fresh(), 3, tiled=True, level_hw=hw, out_format="nhwc_f16")
+    assert torch.equal(x16, want.half())
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    K = L * 49
+    w, b = lgu.ops.pack_encoder_layer(torch.randn(128, K, 1, 1, device="cuda", generator=g) * 0.5,
+                                      torch.randn(128, device="cuda", generator=g) * 0.1)
+    mixed = any(o is None for o in case["offsets"]) and not all(o is None for o in case["offsets"][:L])
+    try:
+        enc = lgu.ops.DefcorrPyramidPlan(tv, fresh(), 3, tiled=True, level_hw=hw, encoder=(w, b))(coords)
+    except lgu._lib.UnsupportedShape:
+        assert mixed   # null-offset patterns the sampler splits into several launches are not fused
+        return
+    ref = torch.relu(x16.permute(0, 2, 3, 1).float() @ w[:, :K].float().t() + b.float()).permute(0, 3, 1, 2)
+    assert bool(((enc.float() - ref).abs() <= ref.abs() * 2.0 ** -10 + 1e-4).all())
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
