@@ -372,7 +372,10 @@ class AltCorrBlock:
         f2_0 = self.pyramid[0][:, jj]
         f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
         # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
-        feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float()
+        # (standard NCHW strides: the cat of permuted views would come out channel-last, which sends the fp32
+        # convolutions below to MIOpen's NHWC implicit-GEMM kernels — 0.89 ms against 0.48 ms for the NCHW ones)
+        feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
+            .contiguous(memory_format=torch.contiguous_format)
         self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
 
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
