@@ -85,6 +85,66 @@ def _solve(A, b, lm, ep):
     return torch.cholesky_solve(b[:, None], chol)[:, 0]
 
 
+class _Plan:
+    """Everything of a BA call that depends only on the graph (ii, jj, t0, t1, motion_only): the index tables of the
+    deterministic assembly, of the accumulations and of the Schur pair enumeration, resident on the device."""
+
+    def __init__(self, lib, ii_h, jj_h, t0, t1, motion_only, dev):
+        P = t1 - t0
+        ts_h = np.arange(t0, t1, dtype=np.int64)
+        ii_exp_h, jj_exp_h = np.concatenate([ts_h, ii_h]), np.concatenate([ts_h, jj_h])
+        kx_h, kk_h = np.unique(ii_exp_h, return_inverse=True)           # :1340-1344
+        kk_h = kk_h.astype(np.int64)
+        self.kx = torch.from_numpy(kx_h).to(dev)
+        self.kk = torch.from_numpy(kk_h).to(dev)
+        self.K = int(kx_h.shape[0])
+        # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
+        bi_h = np.concatenate([ii_h, ii_h, jj_h, jj_h]) - t0
+        bj_h = np.concatenate([ii_h, jj_h, ii_h, jj_h]) - t0
+        self.asm_H = _ScatterSum(lib, np.where((bi_h >= 0) & (bj_h >= 0), bi_h * P + bj_h, -1), dev)
+        self.asm_v = _ScatterSum(lib, np.concatenate([ii_h, jj_h]) - t0, dev)
+        if motion_only:
+            return
+        # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
+        # (grouped by depth frame: the same set of (n, m) pairs as the reference's P x P double loop, in O(pairs))
+        ent = np.nonzero((jj_exp_h >= t0) & (jj_exp_h < t1))[0]
+        ent = ent[np.argsort(kk_h[ent], kind="stable")]
+        _, starts, sizes = np.unique(kk_h[ent], return_index=True, return_counts=True)
+        a_l, c_l, k_l = [], [], []
+        for s0, m_ in zip(starts, sizes):                      # one small outer product per depth frame
+            g = ent[s0:s0 + m_]
+            a_l.append(np.repeat(g, m_)); c_l.append(np.tile(g, m_))
+            k_l.append(np.full(m_ * m_, kk_h[g[0]], np.int64))
+        self.have_pairs = len(a_l) > 0
+        if self.have_pairs:
+            a_n, c_n, k_n = np.concatenate(a_l), np.concatenate(c_l), np.concatenate(k_l)
+        else:
+            a_n = c_n = k_n = np.zeros(1, np.int64)
+        self.trip_t = torch.from_numpy(np.ascontiguousarray(np.stack([a_n, c_n, k_n], 1))).to(dev)
+        self.asm_S = _ScatterSum(lib, (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0) if self.have_pairs else np.zeros(0, np.int64), dev)
+        self.asm_sv = _ScatterSum(lib, jj_exp_h - t0, dev)
+        self.jpose = torch.from_numpy(jj_exp_h - t0).to(dev).contiguous()
+        self.acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
+        self.acc_ii_ts = _Accum(lib, ii_h, ts_h, dev)
+        self.acc_exp_kx = _Accum(lib, ii_exp_h, kx_h, dev)
+
+
+_PLANS = {}       # graph -> _Plan: the factor graph runs many BA calls on one edge set (8-16 per keyframe in the frontend)
+_PLANS_MAX = 8
+
+
+def _plan_for(lib, ii, jj, t0, t1, motion_only, dev):
+    ii_h, jj_h = ii.cpu().numpy().astype(np.int64), jj.cpu().numpy().astype(np.int64)  # the call's one host round trip
+    key = (ii_h.tobytes(), jj_h.tobytes(), int(t0), int(t1), bool(motion_only), str(dev))
+    plan = _PLANS.pop(key, None)
+    if plan is None:
+        plan = _Plan(lib, ii_h, jj_h, int(t0), int(t1), bool(motion_only), dev)
+        while len(_PLANS) >= _PLANS_MAX:
+            _PLANS.pop(next(iter(_PLANS)))
+    _PLANS[key] = plan   # most recently used last
+    return plan
+
+
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
     _check(poses, "poses", disps, "disps", intrinsics, "intrinsics", disps_sens, "disps_sens", targets, "targets",
            weights, "weights")
@@ -99,48 +159,18 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     f32, f64 = torch.float32, torch.float64
     with torch.cuda.device(dev):
         st = _stream(poses)
-        # graph bookkeeping on the host (numpy), once per call
-        ii_h, jj_h = ii.cpu().numpy().astype(np.int64), jj.cpu().numpy().astype(np.int64)
-        ts_h = np.arange(t0, t1, dtype=np.int64)
-        ii_exp_h, jj_exp_h = np.concatenate([ts_h, ii_h]), np.concatenate([ts_h, jj_h])
-        kx_h, kk_h = np.unique(ii_exp_h, return_inverse=True)           # :1340-1344
-        kk_h = kk_h.astype(np.int64)
-        kx = torch.from_numpy(kx_h).to(dev)
-        kk = torch.from_numpy(kk_h).to(dev)
-        # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
-        bi_h = np.concatenate([ii_h, ii_h, jj_h, jj_h]) - t0
-        bj_h = np.concatenate([ii_h, jj_h, ii_h, jj_h]) - t0
-        asm_H = _ScatterSum(lib, np.where((bi_h >= 0) & (bj_h >= 0), bi_h * P + bj_h, -1), dev)
-        asm_v = _ScatterSum(lib, np.concatenate([ii_h, jj_h]) - t0, dev)
+        # graph bookkeeping on the host (numpy): built once per edge set, reused while the graph does not change
+        pl = _plan_for(lib, ii, jj, t0, t1, motion_only, dev)
+        asm_H, asm_v, kx, kk = pl.asm_H, pl.asm_v, pl.kx, pl.kk
         if not motion_only:
-            # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
-            # (grouped by depth frame: the same set of (n, m) pairs as the reference's P x P double loop, in O(pairs))
-            ent = np.nonzero((jj_exp_h >= t0) & (jj_exp_h < t1))[0]
-            ent = ent[np.argsort(kk_h[ent], kind="stable")]
-            _, starts, sizes = np.unique(kk_h[ent], return_index=True, return_counts=True)
-            a_l, c_l, k_l = [], [], []
-            for s0, m_ in zip(starts, sizes):                      # one small outer product per depth frame
-                g = ent[s0:s0 + m_]
-                a_l.append(np.repeat(g, m_)); c_l.append(np.tile(g, m_))
-                k_l.append(np.full(m_ * m_, kk_h[g[0]], np.int64))
-            have_pairs = len(a_l) > 0
-            if have_pairs:
-                a_n, c_n, k_n = np.concatenate(a_l), np.concatenate(c_l), np.concatenate(k_l)
-            else:
-                a_n = c_n = k_n = np.zeros(1, np.int64)
-            trip_t = torch.from_numpy(np.ascontiguousarray(np.stack([a_n, c_n, k_n], 1))).to(dev)
-            asm_S = _ScatterSum(lib, (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0) if have_pairs else np.zeros(0, np.int64), dev)
-            asm_sv = _ScatterSum(lib, jj_exp_h - t0, dev)
-            jpose = torch.from_numpy(jj_exp_h - t0).to(dev)
+            have_pairs, trip_t, asm_S, asm_sv, jpose = pl.have_pairs, pl.trip_t, pl.asm_S, pl.asm_sv, pl.jpose
+            acc_ii_kx, acc_ii_ts, acc_exp_kx = pl.acc_ii_kx, pl.acc_ii_ts, pl.acc_exp_kx
             eta_v = eta.reshape(-1, HW).to(f32).contiguous()
-            K = kx.shape[0]
+            K = pl.K
             if eta_v.shape[0] not in (1, K):
                 raise RuntimeError("ba: eta must have one row per depth frame (%d) or one row, got %d" % (K, eta_v.shape[0]))
             Q = torch.empty((K, HW), dtype=f32, device=dev)
             w = torch.empty((K, HW), dtype=f32, device=dev)
-            acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
-            acc_ii_ts = _Accum(lib, ii_h, ts_h, dev)
-            acc_exp_kx = _Accum(lib, ii_exp_h, kx_h, dev)
 
         Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
         vs = torch.empty((2, E, 6), dtype=f32, device=dev)
@@ -183,7 +213,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                 _lib.check(rc, "ba solve")
             if not motion_only:
                 dw = torch.empty((nE, HW), dtype=f32, device=dev)
-                _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose.contiguous()), _ptr(dw), nE, HW, P, st), "ba EvT")
+                _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose), _ptr(dw), nE, HW, P, st), "ba EvT")
                 dz = torch.empty((K, HW), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_depth_update_f32(_ptr(Q), _ptr(w), _ptr(dw), _ptr(acc_exp_kx.ptrs), _ptr(acc_exp_kx.cols), _ptr(kx),
                                                        _ptr(dz), _ptr(disps), K, HW, st), "ba depth update")  # :1415, :933-946

@@ -210,6 +210,38 @@ def test_hip_ba_is_bit_reproducible(lgu):
 
 
 @pytest.mark.gpu
+def test_hip_ba_plan_cache_follows_the_graph(lgu):
+    """The graph-dependent index tables are cached per edge set (the factor graph runs many BA calls on one graph):
+    a cached plan gives the bits a fresh plan gives, a changed edge list / window / mode gets its own plan, and the
+    cache stays bounded."""
+    rng, intr, poses, disps, ii, jj, targets = scene(23, N=9, H=12, W=16, span=3)
+    p, d = perturb(rng, poses, disps, 1)
+
+    def run(ii_, jj_, tg, t0, motion_only, clear):
+        if clear:
+            lgu.ba._PLANS.clear()
+        pd, dd, idv, sd, td, wd_, ed = _to_dev(p, d, intr, np.zeros_like(d), tg, np.ones_like(tg), np.full(d.shape, 1e-3, f32))
+        iid, jjd = _to_dev(ii_.astype(np.int64), jj_.astype(np.int64))
+        dx, dz = lgu.ba.ba(pd, dd, idv, sd, td, wd_, ed, iid, jjd, t0, len(p), 2, 1e-4, 0.1, motion_only)
+        return [pd.clone(), dd.clone(), dx.clone()] + ([dz.clone()] if dz is not None else [])
+
+    keep = np.arange(len(ii)) % 3 != 0          # a second graph: a third of the edges dropped
+    cases = [(ii, jj, targets, 1, False), (ii[keep], jj[keep], targets[keep], 1, False), (ii, jj, targets, 2, False),
+             (ii, jj, targets, 1, True)]
+    fresh = [run(*c, clear=True) for c in cases]
+    lgu.ba._PLANS.clear()
+    for rep in range(2):                         # second round: every plan comes from the cache
+        for c, want in zip(cases, fresh):
+            got = run(*c, clear=False)
+            assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert len(lgu.ba._PLANS) == len(cases)
+    for k in range(lgu.ba._PLANS_MAX + 3):       # bounded
+        sel = np.arange(len(ii)) != k
+        run(ii[sel], jj[sel], targets[sel], 1, False, clear=False)
+    assert len(lgu.ba._PLANS) == lgu.ba._PLANS_MAX
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("P", [1, 3, 21])
 def test_device_cholesky_solve_against_numpy(lgu, P):
     """lgu_ba_solve_f64: (A + diag(ep + lm diag A)) x = b in one workgroup with the matrix in LDS (6P <= 126, the
