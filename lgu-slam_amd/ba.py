@@ -145,6 +145,74 @@ def _plan_for(lib, ii, jj, t0, t1, motion_only, dev):
     return plan
 
 
+def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v, ii, jj, t0, t1, iterations, lm, ep,
+         motion_only):
+    """The iterations of one call on the current stream.  (Capturable when the window fits the LDS solver; replaying a
+    whole frontend-sized call as one HIP graph was measured and gives nothing — 0.59 ms either way: the call is bound
+    by its kernels, not by its ~40 launches.)"""
+    dev = poses.device
+    E = ii.shape[0]
+    ht, wd = disps.shape[1:]
+    HW = ht * wd
+    P = t1 - t0
+    f32, f64 = torch.float32, torch.float64
+    st = _stream(poses)
+    asm_H, asm_v, kx, kk = pl.asm_H, pl.asm_v, pl.kx, pl.kk
+    if not motion_only:
+        have_pairs, trip_t, asm_S, asm_sv, jpose = pl.have_pairs, pl.trip_t, pl.asm_S, pl.asm_sv, pl.jpose
+        acc_ii_kx, acc_ii_ts, acc_exp_kx = pl.acc_ii_kx, pl.acc_ii_ts, pl.acc_exp_kx
+        K = pl.K
+        Q = torch.empty((K, HW), dtype=f32, device=dev)
+        w = torch.empty((K, HW), dtype=f32, device=dev)
+    Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
+    vs = torch.empty((2, E, 6), dtype=f32, device=dev)
+    Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
+    Eall = torch.empty((P + E, 6, HW), dtype=f32, device=dev)   # E = cat(Ei, Eij) (:1401) without the copy:
+    Eij = Eall[P:]                                               # the build kernel writes Eij in place, Ei is summed into the head
+    scratch = torch.empty((max(E, 1) * lib.lgu_ba_build_slices(E) * 90,), dtype=f32, device=dev)
+    Cii = torch.empty((E, HW), dtype=f32, device=dev)
+    wi = torch.empty((E, HW), dtype=f32, device=dev)
+    dx = torch.zeros((P, 6), dtype=f32, device=dev)
+    dz = None
+    for _ in range(iterations):
+        _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
+                                        _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
+                                        st),
+                   "ba build")
+        A = torch.zeros((P * P, 36), dtype=f64, device=dev)
+        asm_H(Hs.view(-1, 36), A, 1.0, st)
+        b = torch.zeros((P, 6), dtype=f64, device=dev)
+        asm_v(vs.view(-1, 6), b, 1.0, st)
+        if not motion_only:
+            _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
+                                                   _ptr(disps_sens), _ptr(eta_v), eta_v.shape[0], _ptr(Q), _ptr(w), K, HW, st),
+                       "ba depth system")                                                          # :1394-1398
+            acc_ii_ts(Eii.view(E, 6 * HW), st, out=Eall[:P].view(P, 6 * HW))             # :1400-1401
+            nE = P + E
+            S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
+            if have_pairs:
+                _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
+                asm_S(S.view(-1, 36), A, -1.0, st)
+            sv = torch.empty((nE, 6), dtype=f32, device=dev)
+            _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
+            asm_sv(sv, b, -1.0, st)
+        Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
+        dx = torch.empty((P, 6), dtype=f32, device=dev)
+        rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
+        if rc == _lib.LGU_E_UNSUPPORTED:   # more than 21 poses in the window: library Cholesky on the device
+            dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+        else:
+            _lib.check(rc, "ba solve")
+        if not motion_only:
+            dw = torch.empty((nE, HW), dtype=f32, device=dev)
+            _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose), _ptr(dw), nE, HW, P, st), "ba EvT")
+            dz = torch.empty((K, HW), dtype=f32, device=dev)
+            _lib.check(lib.lgu_ba_depth_update_f32(_ptr(Q), _ptr(w), _ptr(dw), _ptr(acc_exp_kx.ptrs), _ptr(acc_exp_kx.cols), _ptr(kx),
+                                                   _ptr(dz), _ptr(disps), K, HW, st), "ba depth update")  # :1415, :933-946
+        _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
+    return [dx, dz]
+
+
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
     _check(poses, "poses", disps, "disps", intrinsics, "intrinsics", disps_sens, "disps_sens", targets, "targets",
            weights, "weights")
@@ -152,70 +220,14 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     _check_dtype(jj, "jj", torch.int64)
     lib = _lib.load()
     dev = poses.device
-    E = ii.shape[0]
-    ht, wd = disps.shape[1:]
-    HW = ht * wd
-    P = t1 - t0
-    f32, f64 = torch.float32, torch.float64
+    HW = disps.shape[1] * disps.shape[2]
     with torch.cuda.device(dev):
-        st = _stream(poses)
         # graph bookkeeping on the host (numpy): built once per edge set, reused while the graph does not change
         pl = _plan_for(lib, ii, jj, t0, t1, motion_only, dev)
-        asm_H, asm_v, kx, kk = pl.asm_H, pl.asm_v, pl.kx, pl.kk
+        eta_v = None
         if not motion_only:
-            have_pairs, trip_t, asm_S, asm_sv, jpose = pl.have_pairs, pl.trip_t, pl.asm_S, pl.asm_sv, pl.jpose
-            acc_ii_kx, acc_ii_ts, acc_exp_kx = pl.acc_ii_kx, pl.acc_ii_ts, pl.acc_exp_kx
-            eta_v = eta.reshape(-1, HW).to(f32).contiguous()
-            K = pl.K
-            if eta_v.shape[0] not in (1, K):
-                raise RuntimeError("ba: eta must have one row per depth frame (%d) or one row, got %d" % (K, eta_v.shape[0]))
-            Q = torch.empty((K, HW), dtype=f32, device=dev)
-            w = torch.empty((K, HW), dtype=f32, device=dev)
-
-        Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
-        vs = torch.empty((2, E, 6), dtype=f32, device=dev)
-        Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
-        Eall = torch.empty((P + E, 6, HW), dtype=f32, device=dev)   # E = cat(Ei, Eij) (:1401) without the copy:
-        Eij = Eall[P:]                                               # the build kernel writes Eij in place, Ei is summed into the head
-        scratch = torch.empty((max(E, 1) * lib.lgu_ba_build_slices(E) * 90,), dtype=f32, device=dev)
-        Cii = torch.empty((E, HW), dtype=f32, device=dev)
-        wi = torch.empty((E, HW), dtype=f32, device=dev)
-        dx = torch.zeros((P, 6), dtype=f32, device=dev)
-        dz = None
-        for _ in range(iterations):
-            _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
-                                            _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
-                                            st),
-                       "ba build")
-            A = torch.zeros((P * P, 36), dtype=f64, device=dev)
-            asm_H(Hs.view(-1, 36), A, 1.0, st)
-            b = torch.zeros((P, 6), dtype=f64, device=dev)
-            asm_v(vs.view(-1, 6), b, 1.0, st)
-            if not motion_only:
-                _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
-                                                       _ptr(disps_sens), _ptr(eta_v), eta_v.shape[0], _ptr(Q), _ptr(w), K, HW, st),
-                           "ba depth system")                                                          # :1394-1398
-                acc_ii_ts(Eii.view(E, 6 * HW), st, out=Eall[:P].view(P, 6 * HW))             # :1400-1401
-                nE = P + E
-                S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
-                if have_pairs:
-                    _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
-                    asm_S(S.view(-1, 36), A, -1.0, st)
-                sv = torch.empty((nE, 6), dtype=f32, device=dev)
-                _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
-                asm_sv(sv, b, -1.0, st)
-            Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
-            dx = torch.empty((P, 6), dtype=f32, device=dev)
-            rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
-            if rc == _lib.LGU_E_UNSUPPORTED:   # more than 21 poses in the window: library Cholesky on the device
-                dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
-            else:
-                _lib.check(rc, "ba solve")
-            if not motion_only:
-                dw = torch.empty((nE, HW), dtype=f32, device=dev)
-                _lib.check(lib.lgu_ba_evt_f32(_ptr(Eall), _ptr(dx), _ptr(jpose), _ptr(dw), nE, HW, P, st), "ba EvT")
-                dz = torch.empty((K, HW), dtype=f32, device=dev)
-                _lib.check(lib.lgu_ba_depth_update_f32(_ptr(Q), _ptr(w), _ptr(dw), _ptr(acc_exp_kx.ptrs), _ptr(acc_exp_kx.cols), _ptr(kx),
-                                                       _ptr(dz), _ptr(disps), K, HW, st), "ba depth update")  # :1415, :933-946
-            _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
-    return [dx, dz]
+            eta_v = eta.reshape(-1, HW).to(torch.float32).contiguous()
+            if eta_v.shape[0] not in (1, pl.K):
+                raise RuntimeError("ba: eta must have one row per depth frame (%d) or one row, got %d" % (pl.K, eta_v.shape[0]))
+        return _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v, ii, jj, t0, t1, iterations, lm, ep,
+                    motion_only)

@@ -401,8 +401,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_disp_retr_kernel(float* disps, 
 
 // ---- reduced camera system: damping + blocked Cholesky + solve in ONE workgroup (SparseBlock::solve :1206-1231) ----
 // A (n x n, n = 6 P, row-major double, symmetric) and b (n) stay untouched; x (P,6) float.  The matrix lives in LDS
-// (n <= 126: 127 KB), factorised by 6 x 6 block columns: diagonal block by one thread, panel solve with lanes over
-// rows, trailing update with lanes over (row, column-block) pairs; then the two triangular solves.  Not positive
+// (n <= 126: 127 KB), factorised by 6 x 6 block columns: diagonal block by one thread in registers, panel solve with
+// lanes over rows, trailing update with lanes over (row, column) pairs; then the two triangular solves by one wave.  Not positive
 // definite (a pivot <= 0 or not finite): x = 0, as the reference does when Eigen reports failure.
 constexpr int BA_SOLVE_MAXN = 126;
 __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __restrict__ A, const double* __restrict__ b,
@@ -423,19 +423,32 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
   const int nb = n / 6;
   for (int kb = 0; kb < nb; kb++) {
     const int k0 = kb * 6;
-    if (threadIdx.x == 0) {  // 6 x 6 diagonal block
-      for (int k = k0; k < k0 + 6; k++) {
-        double d = Ls[k * ld + k];
-        for (int p = k0; p < k; p++) d -= Ls[k * ld + p] * Ls[k * ld + p];
+    if (threadIdx.x == 0) {  // 6 x 6 diagonal block, factorised in registers (no dependent LDS round trips)
+      double a[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) a[i][j] = Ls[(k0 + i) * ld + k0 + j];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        double d = a[k][k];
+#pragma unroll
+        for (int p = 0; p < k; p++) d -= a[k][p] * a[k][p];
         if (!(d > 0.0) || !(d < 1e300)) { bad = 1; d = 1.0; }
         d = sqrt(d);
-        Ls[k * ld + k] = d;
-        for (int i = k + 1; i < k0 + 6; i++) {
-          double v = Ls[i * ld + k];
-          for (int p = k0; p < k; p++) v -= Ls[i * ld + p] * Ls[k * ld + p];
-          Ls[i * ld + k] = v / d;
+        a[k][k] = d;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+          double v = a[i][k];
+#pragma unroll
+          for (int p = 0; p < k; p++) v -= a[i][p] * a[k][p];
+          a[i][k] = v / d;
         }
       }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Ls[(k0 + i) * ld + k0 + j] = a[i][j];
     }
     __syncthreads();
     // panel: rows below the block solve L_ik L_kk^T = A_ik
@@ -459,17 +472,32 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && !bad) {  // L y = b, L^T x = y (n <= 126: a few thousand operations)
-    for (int i = 0; i < n; i++) {
-      double v = y[i];
-      for (int p = 0; p < i; p++) v -= Ls[i * ld + p] * y[p];
-      y[i] = v / Ls[i * ld + i];
+  // L y = b, L^T x = y by ONE wave, column by column: lane l holds entries l and l + 64 of the right-hand side
+  // (n <= 126), the pivot entry is broadcast with v_readlane and every lane updates its own entries — 2 n dependent
+  // steps of ~200 cycles instead of n^2 serial operations of one thread.  Forward: the subtractions reach every entry
+  // in the order of the row-by-row loop (ascending column), so L y = b is bit-identical to it.
+  if (threadIdx.x < kWave && !bad) {
+    const int l = threadIdx.x;
+    double y0 = l < n ? y[l] : 0.0, y1 = l + kWave < n ? y[l + kWave] : 0.0;
+    auto bcast = [](double v, int src) {
+      const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+      const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+      return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    for (int i = 0; i < n; i++) {  // forward
+      const double yi = bcast(i < kWave ? y0 : y1, i & (kWave - 1)) / Ls[i * ld + i];
+      if (l == (i & (kWave - 1))) { if (i < kWave) y0 = yi; else y1 = yi; }
+      if (l > i && l < n) y0 -= Ls[l * ld + i] * yi;
+      if (l + kWave > i && l + kWave < n) y1 -= Ls[(l + kWave) * ld + i] * yi;
     }
-    for (int i = n - 1; i >= 0; i--) {
-      double v = y[i];
-      for (int p = i + 1; p < n; p++) v -= Ls[p * ld + i] * y[p];
-      y[i] = v / Ls[i * ld + i];
+    for (int i = n - 1; i >= 0; i--) {  // backward: row i of L is column i of L^T
+      const double xi = bcast(i < kWave ? y0 : y1, i & (kWave - 1)) / Ls[i * ld + i];
+      if (l == (i & (kWave - 1))) { if (i < kWave) y0 = xi; else y1 = xi; }
+      if (l < i) y0 -= Ls[i * ld + l] * xi;
+      if (l + kWave < i) y1 -= Ls[i * ld + l + kWave] * xi;
     }
+    if (l < n) y[l] = y0;
+    if (l + kWave < n) y[l + kWave] = y1;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += BA_THREADS) x[i] = bad ? 0.0f : (float)y[i];

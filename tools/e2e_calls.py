@@ -86,8 +86,11 @@ with torch.no_grad():
     eta = torch.full((N, h, w), 1e-3, device=dev)
     sens = torch.zeros_like(disps)
 
+    pbuf, dbuf = poses.clone(), disps.clone()   # persistent state buffers, as depth_video holds them
+
     def run_ba():
-        lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, iib, jjb, 2, N, 2, 1e-4, 0.1, False)
+        pbuf.copy_(poses); dbuf.copy_(disps)
+        lgu.ba.ba(pbuf, dbuf, intr, sens, tgt, wgt, eta, iib, jjb, 2, N, 2, 1e-4, 0.1, False)
 
     res["ba: 12 keyframes 48x64, %d edges, 2 iterations (ms, wall incl. host bookkeeping)" % len(ii_l)] = wall(run_ba, iters=10, warm=2)
     # backend-sized BA: 200 keyframes of 60x80, edges within 5 frames (1970 edges), window [1, 200), 2 iterations
