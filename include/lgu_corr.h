@@ -147,6 +147,19 @@ int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge
                                     int L, int E, int H1, int W1, const int* H2, const int* W2,
                                     int radius, int enc_n, int flags, void* stream);
 
+/* The level-0 offset head of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:174-189, :220:
+ * ofsMap(cat(fmap[ii] * 4, fmap[jj] * 4).float()), a Conv2d(2C, Cout, 3, padding=1) evaluated in fp32) straight from the
+ * stored half frame buffers, on the half matrix cores with fp32-accurate weights:
+ *   frames (NF, H, W, C) half, channel-last (AltCorrBlock.pyramid[0], = fmap / 4);  ii, jj (E) int64 frame indices;
+ *   wpack: the weight times 4 (exact), split into two half parts hi + lo (22 significant bits) and laid out in MFMA
+ *          fragment order [9 taps][2C/32][hi, lo][7][64 lanes][8] (lgu_slam_amd.ops.pack_offset_conv builds it);
+ *   bias (Cout) fp32;  out (E, Cout, H, W) fp32 fully written.
+ * Half x half products are exact in fp32 and accumulation is fp32, so the result equals the fp32 convolution up to the
+ * 2^-22 truncation of the weights (below that convolution's own summation noise).  C % 32 == 0, Cout <= 112;
+ * otherwise LGU_E_UNSUPPORTED. */
+int lgu_offset_conv_frames_h16(const void* frames, const long long* ii, const long long* jj, const void* wpack,
+                               const float* bias, float* out, int E, int H, int W, int C, int Cout, void* stream);
+
 /* Post-processing of the learned sampling offsets (reference droid_slam/modules/corr.py:117-135 and :217-235 with
  * per_Corr_Normalization, gaussianMask_cuda.py:26-33) in one pass:
  *   o0 (E,C,H,W), o1 (E,C,Hl,Wl): the outputs of the two offset convolutions (o1 still at the pooled resolution; the

@@ -362,6 +362,38 @@ class AltCorrBlock:
             self.pyramid.append(lvl.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
             lvl = F.avg_pool2d(lvl, 2, stride=2)
 
+    def _offsets_from_frames(self, B, ii, jj):
+        """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): the level-0
+        head runs on the matrix cores straight from the stored frames (ops.offset_conv_frames: no gather / x 4 / cat /
+        cast of a (E,256,H,W) tensor, fp32-accurate split-half weights), the residual head takes the 2 x 2 average of
+        the frames, which is pooled ONCE per block instead of per call (the same fp32 averages of the same numbers:
+        pooling commutes with the per-edge gather), and the rest is finish_offsets.  Sets self.offset; returns False
+        when the general composition has to run."""
+        conv = self.ofsMap
+        C = self.pyramid[0].shape[-1]
+        if not (FUSED_OFFSETS and B == 1 and self.num_levels >= 2 and self.pyramid[0].dtype == torch.float16
+                and self.pyramid[0].is_cuda and not torch.is_autocast_enabled() and ii.dtype == torch.int64
+                and jj.dtype == torch.int64 and isinstance(conv, torch.nn.Conv2d) and conv.bias is not None
+                and conv.in_channels == 2 * C and C % 32 == 0 and conv.out_channels <= 112
+                and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (conv.weight.requires_grad or any(q.requires_grad for q in self.ofs_residual.parameters())))):
+            return False
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+        if getattr(self, "_ofs_key", None) != key:
+            self._ofs_packed = ops.pack_offset_conv(conv.weight, conv.bias)
+            self._ofs_key = key
+        frames0 = self.pyramid[0][0]
+        if getattr(self, "_pooled4", None) is None:
+            self._pooled4 = F.avg_pool2d((frames0 * 4.0).permute(0, 3, 1, 2).float().contiguous(), kernel_size=2, stride=2)
+        try:
+            o0 = ops.offset_conv_frames(frames0, ii.contiguous(), jj.contiguous(), self._ofs_packed)
+        except _lib.UnsupportedShape:
+            return False
+        o1_low = self.ofs_residual(torch.cat((self._pooled4[ii], self._pooled4[jj]), dim=1))
+        self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels)
+        return True
+
     def corr_fn(self, coords, ii, jj):
         B, N, H, W, S, _ = coords.shape
         rd = 2 * self.radius + 1
@@ -369,14 +401,22 @@ class AltCorrBlock:
 
         f1 = self.pyramid[0][:, ii]
         f1 = f1.reshape((B * N,) + f1.shape[2:])
-        f2_0 = self.pyramid[0][:, jj]
-        f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
-        # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
-        # (standard NCHW strides: the cat of permuted views would come out channel-last, which sends the fp32
-        # convolutions below to MIOpen's NHWC implicit-GEMM kernels — 0.89 ms against 0.48 ms for the NCHW ones)
-        feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
-            .contiguous(memory_format=torch.contiguous_format)
-        self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+
+        def make_feats():
+            # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
+            # (standard NCHW strides: the cat of permuted views would come out channel-last, which sends the fp32
+            # convolutions below to MIOpen's NHWC implicit-GEMM kernels — 0.89 ms against 0.48 ms for the NCHW ones)
+            f2_0 = self.pyramid[0][:, jj]
+            f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
+            return torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
+                .contiguous(memory_format=torch.contiguous_format)
+
+        feats = None
+        if not self._offsets_from_frames(B, ii, jj):
+            feats = make_feats()
+            self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+        else:
+            zero_level = self._zero_level
 
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
         # operators take exact half products, accumulate in fp32 and equal the reference's `.float()`
@@ -404,7 +444,8 @@ class AltCorrBlock:
                 return fused.view(B, N, -1, H, W).unsqueeze(-1)   # (1,E,L*rd*rd,H,W,S=1)
             except _lib.UnsupportedShape:
                 # channel counts / radii the matrix-core kernel does not serve: per-level operators below
-                self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+                self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats if feats is not None else make_feats(),
+                                                  self.num_levels)
         out = []
         for i in range(self.num_levels):
             f2 = self.pyramid[i][:, jj]

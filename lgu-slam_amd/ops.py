@@ -440,6 +440,48 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+def pack_offset_conv(weight, bias, scale=4.0):
+    """Operands of lgu_offset_conv_frames_h16 from a Conv2d(2C, Cout, 3, padding=1)'s parameters: the weight times
+    `scale` (AltCorrBlock feeds the convolution 4 x the stored frames; a power of two, exact) split into two half parts
+    hi + lo and laid out in MFMA fragment order.  Returns (wpack, bias_fp32, Cout, C)."""
+    Cout, C2, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or C2 % 64 != 0 or Cout > 112 or bias is None:
+        raise RuntimeError("pack_offset_conv: expected a 3x3 convolution with bias, <= 112 output and 64 k input channels")
+    w = torch.zeros((112, C2, 9), dtype=torch.float32, device=weight.device)
+    w[:Cout] = (weight.detach().float() * scale).reshape(Cout, C2, 9)
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    ks = C2 // 32
+
+    def frag(t):   # (112, C2, 9) -> [tap][kstep][ntile][kg][nl][8]
+        return t.view(7, 16, ks, 4, 8, 9).permute(5, 2, 0, 3, 1, 4)
+
+    wpack = torch.stack((frag(hi), frag(lo)), dim=2).contiguous()   # [tap][kstep][part][ntile][kg][nl][8]
+    return wpack, bias.detach().float().contiguous(), Cout, C2 // 2
+
+
+def offset_conv_frames(frames, ii, jj, packed):
+    """ofsMap(cat(frames[ii] * 4, frames[jj] * 4).float()) of AltCorrBlock.corr_fn (reference corr.py:174-189, :220)
+    without materialising its input: frames (NF,H,W,C) half channel-last, ii / jj (E) int64, packed from
+    pack_offset_conv.  Returns (E, Cout, H, W) fp32."""
+    wpack, bias, Cout, C = packed
+    _check_dtype(frames, "frames", torch.float16)
+    _check_dtype(ii, "ii", torch.int64)
+    _check_dtype(jj, "jj", torch.int64)
+    NF, H, W, Cf = frames.shape
+    if Cf != C or not frames.is_contiguous():
+        raise RuntimeError("offset_conv_frames: frames must be contiguous (NF,H,W,%d)" % C)
+    E = ii.shape[0]
+    out = torch.empty((E, Cout, H, W), dtype=torch.float32, device=frames.device)
+    if E == 0:
+        return out
+    with torch.cuda.device(frames.device):
+        rc = _lib.load().lgu_offset_conv_frames_h16(_ptr(frames), _ptr(ii), _ptr(jj), _ptr(wpack), _ptr(bias), _ptr(out), E, H, W, C,
+                                                    Cout, _stream(frames))
+    _lib.check(rc, "offset_conv_frames")
+    return out
+
+
 def offsets_finalize(o0, o1_lowres, eps=1e-5, autocast=None):
     """Post-processing of the two offset convolutions' outputs (reference corr.py:117-135 / :217-235) in one pass:
     per-sample standardisation, 4*tanh, the level-1 residual mix, nearest upsampling of the pooled-resolution head and

@@ -842,6 +842,68 @@ def test_fused_offset_post_processing_equals_the_torch_composition(lgu, shape, h
         assert float(want[l].float().abs().max()) > 1.0
 
 
+@pytest.mark.parametrize("cfg", [(16, 8, 60, 80), (3, 4, 13, 21), (5, 3, 24, 32), (1, 2, 7, 9)])
+def test_offset_head_on_the_matrix_cores_equals_the_fp32_convolution(lgu, cfg):
+    """lgu_offset_conv_frames_h16: ofsMap(cat(frames[ii] * 4, frames[jj] * 4).float()) of AltCorrBlock.corr_fn
+    (reference corr.py:174-189, :220) read straight from the half frame buffers, weights split into two half parts.
+    Against the module's fp32 convolution on the materialised input: <= 1e-5 of the output range (the split truncates
+    the weights at 2^-22; the library convolution itself is 1e-6 away from an fp64 evaluation).  Odd sizes exercise the
+    image border, partial pixel tiles and the unaligned store path."""
+    E, NF, H, W = cfg
+    torch.manual_seed(E * 100 + H)
+    conv = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    frames = (torch.randn(NF, H, W, 128, device="cuda") * 0.5 / 4).half()
+    ii = torch.randint(0, NF, (E,), device="cuda")
+    jj = torch.randint(0, NF, (E,), device="cuda")
+    with torch.no_grad():
+        feats = torch.cat(((frames[ii] * 4.0).permute(0, 3, 1, 2), (frames[jj] * 4.0).permute(0, 3, 1, 2)), dim=1).float().contiguous()
+        want = conv(feats)
+        want64 = torch.nn.functional.conv2d(feats.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        packed = lgu.ops.pack_offset_conv(conv.weight, conv.bias)
+        got = lgu.ops.offset_conv_frames(frames, ii, jj, packed)
+    assert tuple(got.shape) == (E, 98, H, W) and got.dtype == torch.float32
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale
+    assert float((got.double() - want64).abs().max()) <= 4 * max(float((want.double() - want64).abs().max()), 1e-7 * scale)
+
+
+def test_altcorrblock_offsets_from_frames_equal_the_general_composition(lgu, monkeypatch):
+    """AltCorrBlock's inference fast path for a half pyramid (level-0 head on the matrix cores from the stored frames,
+    residual head on frames pooled once per block) against the reference-shaped composition (gather, x 4, cat, float,
+    two fp32 convolutions): offsets equal to 2e-5 (values in [-4, 4]; the split-half weights move the convolution
+    output by ~2e-6, which 4 tanh(x / std) amplifies), the lookup to 1e-4 of its range; repeated calls reuse the
+    pooled frames."""
+    import lgu_slam_amd.corr as corr_mod
+    torch.manual_seed(41)
+    N, H, W, E = 5, 24, 32, 7
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    fm = (torch.randn(1, N, 128, H, W, device="cuda") * 0.5).half()
+    ii = torch.randint(0, N, (E,), device="cuda")
+    jj = torch.randint(0, N, (E,), device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, E, H, W, 2, device="cuda")).unsqueeze(-2)
+    with torch.no_grad():
+        alt = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
+        assert alt._offsets_from_frames(1, ii, jj)
+        fast_off = [o.clone() for o in alt.offset[:2]]
+        out_fast = alt(coords, ii, jj).clone()
+        out_fast2 = alt(coords, ii, jj)   # pooled frames and packed weights reused (the library's residual convolution may
+        assert float((out_fast - out_fast2).abs().max()) <= 1e-5 * float(out_fast.abs().max())   # switch algorithm after its first run)
+        monkeypatch.setattr(corr_mod, "FUSED_OFFSETS", False)
+        ref = lgu.AltCorrBlock(ofsMap, ofsRes, None, fm)
+        assert not ref._offsets_from_frames(1, ii, jj)
+        out_ref = ref(coords, ii, jj)
+        f1 = ref.pyramid[0][0][ii]
+        f2 = ref.pyramid[0][0][jj]
+        feats = torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2 * 4.0).permute(0, 3, 1, 2)), dim=1).float().contiguous()
+        ref_off, _ = corr_mod.generate_offsets(ofsMap, ofsRes, feats, 4)
+    for a_, b_ in zip(fast_off, ref_off[:2]):
+        assert float((a_ - b_.float()).abs().max()) <= 2e-5
+    assert tuple(out_fast.shape) == tuple(out_ref.shape)
+    assert float((out_fast - out_ref).abs().max()) <= 1e-4 * float(out_ref.abs().max())
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]
