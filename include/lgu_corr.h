@@ -155,10 +155,13 @@ int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge
  *          fragment order [9 taps][2C/32][hi, lo][7][64 lanes][8] (lgu_slam_amd.ops.pack_offset_conv builds it);
  *   bias (Cout) fp32;  out (E, Cout, H, W) fp32 fully written.
  * Half x half products are exact in fp32 and accumulation is fp32, so the result equals the fp32 convolution up to the
- * 2^-22 truncation of the weights (below that convolution's own summation noise).  C % 32 == 0, Cout <= 112;
- * otherwise LGU_E_UNSUPPORTED. */
-int lgu_offset_conv_frames_h16(const void* frames, const long long* ii, const long long* jj, const void* wpack,
-                               const float* bias, float* out, int E, int H, int W, int C, int Cout, void* stream);
+ * 2^-22 truncation of the weights (below that convolution's own summation noise).  frames_lo (may be NULL): a second
+ * half part of the input, same layout — input = frames + frames_lo — for inputs that need up to 24 bits (the residual
+ * head of :219-220 takes 2 x 2 averages of the frames; split as hi = half(x), lo = half(x - hi)).  C % 32 == 0,
+ * Cout <= 112; otherwise LGU_E_UNSUPPORTED. */
+int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const long long* ii, const long long* jj,
+                               const void* wpack, const float* bias, float* out, int E, int H, int W, int C, int Cout,
+                               void* stream);
 
 /* Post-processing of the learned sampling offsets (reference droid_slam/modules/corr.py:117-135 and :217-235 with
  * per_Corr_Normalization, gaussianMask_cuda.py:26-33) in one pass:

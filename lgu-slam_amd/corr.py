@@ -363,12 +363,12 @@ class AltCorrBlock:
             lvl = F.avg_pool2d(lvl, 2, stride=2)
 
     def _offsets_from_frames(self, B, ii, jj):
-        """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): the level-0
-        head runs on the matrix cores straight from the stored frames (ops.offset_conv_frames: no gather / x 4 / cat /
-        cast of a (E,256,H,W) tensor, fp32-accurate split-half weights), the residual head takes the 2 x 2 average of
-        the frames, which is pooled ONCE per block instead of per call (the same fp32 averages of the same numbers:
-        pooling commutes with the per-edge gather), and the rest is finish_offsets.  Sets self.offset; returns False
-        when the general composition has to run."""
+        """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
+        run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
+        (E,256,H,W) tensor, fp32-accurate split-half weights).  The residual head's input, the 2 x 2 average of the
+        frames, is pooled ONCE per block instead of per call (the same fp32 averages of the same numbers: pooling
+        commutes with the per-edge gather) and split into two half parts.  The rest is finish_offsets.  Sets
+        self.offset; returns False when the general composition has to run."""
         conv = self.ofsMap
         C = self.pyramid[0].shape[-1]
         if not (FUSED_OFFSETS and B == 1 and self.num_levels >= 2 and self.pyramid[0].dtype == torch.float16
@@ -379,18 +379,38 @@ class AltCorrBlock:
                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
                 and not (torch.is_grad_enabled() and (conv.weight.requires_grad or any(q.requires_grad for q in self.ofs_residual.parameters())))):
             return False
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+        res = self.ofs_residual
+        res_fast = (isinstance(res, torch.nn.Conv2d) and res.bias is not None and res.in_channels == 2 * C
+                    and res.out_channels <= 112 and res.kernel_size == (3, 3) and res.padding == (1, 1)
+                    and res.stride == (1, 1) and res.dilation == (1, 1) and res.groups == 1
+                    and res.weight.dtype == torch.float32)
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version,
+               tuple((q.data_ptr(), q._version) for q in res.parameters()))
         if getattr(self, "_ofs_key", None) != key:
             self._ofs_packed = ops.pack_offset_conv(conv.weight, conv.bias)
+            self._res_packed = ops.pack_offset_conv(res.weight, res.bias) if res_fast else None
             self._ofs_key = key
         frames0 = self.pyramid[0][0]
-        if getattr(self, "_pooled4", None) is None:
-            self._pooled4 = F.avg_pool2d((frames0 * 4.0).permute(0, 3, 1, 2).float().contiguous(), kernel_size=2, stride=2)
+        if getattr(self, "_pooled", None) is None:
+            # 2 x 2 averages of the frames in fp32, as avg_pool2d of the reference's fp32 input gives them (x 4 is a power
+            # of two and moves to the weights exactly), channel-last, split into two half parts: hi + lo == the average
+            # to 2^-22.  The general path keeps the fp32 averages (x 4) in NCHW.
+            pooled = F.avg_pool2d(frames0.permute(0, 3, 1, 2).float(), kernel_size=2, stride=2)
+            if res_fast:
+                pl_ = pooled.permute(0, 2, 3, 1).contiguous()
+                hi = pl_.half()
+                self._pooled = (hi, (pl_ - hi.float()).half())
+            else:
+                self._pooled = (pooled * 4.0,)
+        iic, jjc = ii.contiguous(), jj.contiguous()
         try:
-            o0 = ops.offset_conv_frames(frames0, ii.contiguous(), jj.contiguous(), self._ofs_packed)
+            o0 = ops.offset_conv_frames(frames0, iic, jjc, self._ofs_packed)
+            if len(self._pooled) == 2:
+                o1_low = ops.offset_conv_frames(self._pooled[0], iic, jjc, self._res_packed, frames_lo=self._pooled[1])
+            else:
+                o1_low = res(torch.cat((self._pooled[0][ii], self._pooled[0][jj]), dim=1))
         except _lib.UnsupportedShape:
             return False
-        o1_low = self.ofs_residual(torch.cat((self._pooled4[ii], self._pooled4[jj]), dim=1))
         self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels)
         return True
 

@@ -1,4 +1,4 @@
-// offconv.hip — the level-0 offset head of AltCorrBlock on the matrix cores (gfx950).
+// offconv.hip — the offset heads of AltCorrBlock on the matrix cores (gfx950).
 //
 // Reference (droid_slam/modules/corr.py:174-189, :217-220): every call of AltCorrBlock.corr_fn gathers the two frames of
 // each edge, multiplies by 4, concatenates to (E, 256, H, W), casts to fp32 and runs ofsMap = Conv2d(256, 98, 3,
@@ -19,7 +19,8 @@
 // gather, no concatenation, no cast.  B (weights) is prepacked on the host in MFMA fragment order, 14 KiB per K step
 // (2 parts x 7 tiles x 1 KiB), streamed into a double-buffered LDS area by LDS-DMA one step ahead and read back
 // lane-linearly.  Output (E, 98, H, W) fp32 with the bias added: a lane owns 4 consecutive pixels of one channel = one
-// 16-byte store.
+// 16-byte store.  The residual head (corr.py:219-220: ofs_residual on the 2 x 2 average of that input) is the same
+// kernel over frames pooled once per block, with the input in two half parts as well (template LO).
 #include "lgu_common.hpp"
 
 namespace lgu {
@@ -36,6 +37,7 @@ typedef const __attribute__((address_space(1))) void oc_glb_void;
 
 struct OffConvParams {
   const _Float16* frames;  // (NF, H, W, C) channel-last, C = 128
+  const _Float16* frames_lo;  // LO kernels: second half part of the input (input = frames + frames_lo), same layout
   const long long* ii;     // (E) frame of channels 0..C-1
   const long long* jj;     // (E) frame of channels C..2C-1
   const _Float16* wpack;   // [9][KS][2][OC_NT][64][8] halves, KS = 2C / 32
@@ -44,6 +46,9 @@ struct OffConvParams {
   int E, H, W, C, Cout, KS;
 };
 
+// LO: the input has two half parts (e.g. 2 x 2 averages of half values, which need up to 24 bits): x = hi + lo and
+// x . W' = hi . whi + hi . wlo + lo . whi + lo . wlo.
+template <bool LO>
 __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const OffConvParams p) {
   extern __shared__ float4 oc_smem[];  // 2 x OC_CHUNK
   char* const wbuf = reinterpret_cast<char*>(oc_smem);
@@ -53,8 +58,7 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
   const int HW = p.H * p.W;
   const int lr = lane & 15, kg = lane >> 4;
   const size_t fstride = (size_t)HW * p.C;
-  const _Float16* const f1 = p.frames + (size_t)p.ii[e] * fstride;
-  const _Float16* const f2 = p.frames + (size_t)p.jj[e] * fstride;
+  const size_t o1 = (size_t)p.ii[e] * fstride, o2 = (size_t)p.jj[e] * fstride;
   const int ksh = p.KS >> 1;  // K steps per frame
 
   // this lane's A-row pixel in each of the wave's tiles
@@ -84,28 +88,33 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
       if (k * 4096 + w * 1024 < OC_CHUNK)
         __builtin_amdgcn_global_load_lds((oc_glb_void*)(src + k * 4096), (oc_lds_void*)(dst + k * 4096), 16, 0, 0);
   };
-  auto load_a = [&](int s, oc_half8 (&a)[OC_MT]) {
+  auto load_a = [&](int s, oc_half8 (&a)[OC_MT], oc_half8 (&al)[OC_MT]) {
     const int tap = s / p.KS, ks = s - tap * p.KS;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    const _Float16* const fb = (ks < ksh ? f1 : f2) + (ks < ksh ? ks : ks - ksh) * 32 + kg * 8;
+    const size_t fo = (ks < ksh ? o1 : o2) + (ks < ksh ? ks : ks - ksh) * 32 + kg * 8;
 #pragma unroll
     for (int t = 0; t < OC_MT; t++) {
       const int yy = py[t] + dy, xx = px[t] + dx;
       const bool ok = pv[t] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
       a[t] = oc_half8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) a[t] = *reinterpret_cast<const oc_half8*>(fb + ((size_t)yy * p.W + xx) * p.C);
+      if (LO) al[t] = a[t];
+      if (ok) {
+        const size_t off = fo + ((size_t)yy * p.W + xx) * p.C;
+        a[t] = *reinterpret_cast<const oc_half8*>(p.frames + off);
+        if (LO) al[t] = *reinterpret_cast<const oc_half8*>(p.frames_lo + off);
+      }
     }
   };
 
-  oc_half8 a_cur[OC_MT], a_nxt[OC_MT];
+  oc_half8 a_cur[OC_MT], a_nxt[OC_MT], l_cur[OC_MT], l_nxt[OC_MT];
   stage(0);
-  load_a(0, a_cur);
+  load_a(0, a_cur, l_cur);
   for (int s = 0; s < nsteps; s++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk s has landed (this wave's part) and a_cur is here
     __syncthreads();                                  // ... everyone's part; buffer (s + 1) & 1 is no longer read
     if (s + 1 < nsteps) {
       stage(s + 1);
-      load_a(s + 1, a_nxt);
+      load_a(s + 1, a_nxt, l_nxt);
     }
     const char* const wb = wbuf + (s & 1) * OC_CHUNK + lane * 16;
 #pragma unroll
@@ -116,10 +125,17 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
       for (int t = 0; t < OC_MT; t++) {
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[t], bh, acc[t][n], 0, 0, 0);
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[t], bl, acc[t][n], 0, 0, 0);
+        if (LO) {
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l_cur[t], bh, acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l_cur[t], bl, acc[t][n], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
-    for (int t = 0; t < OC_MT; t++) a_cur[t] = a_nxt[t];
+    for (int t = 0; t < OC_MT; t++) {
+      a_cur[t] = a_nxt[t];
+      if (LO) l_cur[t] = l_nxt[t];
+    }
   }
 
   // C layout: lane (kg, lr) holds pixels 4 kg .. 4 kg + 3 of the tile for channel tile*16 + lr
@@ -148,21 +164,26 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
 
 extern "C" {
 
-int lgu_offset_conv_frames_h16(const void* frames, const long long* ii, const long long* jj, const void* wpack,
-                               const float* bias, float* out, int E, int H, int W, int C, int Cout, void* stream) {
+int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const long long* ii, const long long* jj,
+                               const void* wpack, const float* bias, float* out, int E, int H, int W, int C, int Cout,
+                               void* stream) {
   using namespace lgu;
   if (!frames || !ii || !jj || !wpack || !bias || !out) return LGU_E_BADARG;
   if (E < 0 || H < 1 || W < 1 || C < 1 || Cout < 1) return LGU_E_BADARG;
   if (C % 32 != 0 || Cout > OC_NT * 16 || E > 65535 ||
-      ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(wpack) | reinterpret_cast<uintptr_t>(out)) & 15) != 0)
+      ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(frames_lo) | reinterpret_cast<uintptr_t>(wpack) |
+        reinterpret_cast<uintptr_t>(out)) & 15) != 0)
     return LGU_E_UNSUPPORTED;
   if (E == 0) return LGU_OK;
   OffConvParams p;
-  p.frames = static_cast<const _Float16*>(frames); p.ii = ii; p.jj = jj;
+  p.frames = static_cast<const _Float16*>(frames); p.frames_lo = static_cast<const _Float16*>(frames_lo); p.ii = ii; p.jj = jj;
   p.wpack = static_cast<const _Float16*>(wpack); p.bias = bias; p.out = out;
   p.E = E; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.KS = 2 * C / 32;
   const dim3 grid((H * W + OC_PIX - 1) / OC_PIX, E);
-  hipLaunchKernelGGL(offconv_frames_kernel, grid, dim3(OC_WAVES * kWave), 2 * OC_CHUNK, reinterpret_cast<hipStream_t>(stream), p);
+  if (frames_lo)
+    hipLaunchKernelGGL(offconv_frames_kernel<true>, grid, dim3(OC_WAVES * kWave), 2 * OC_CHUNK, reinterpret_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(offconv_frames_kernel<false>, grid, dim3(OC_WAVES * kWave), 2 * OC_CHUNK, reinterpret_cast<hipStream_t>(stream), p);
   return launch_status();
 }
 

@@ -460,12 +460,17 @@ def pack_offset_conv(weight, bias, scale=4.0):
     return wpack, bias.detach().float().contiguous(), Cout, C2 // 2
 
 
-def offset_conv_frames(frames, ii, jj, packed):
+def offset_conv_frames(frames, ii, jj, packed, frames_lo=None):
     """ofsMap(cat(frames[ii] * 4, frames[jj] * 4).float()) of AltCorrBlock.corr_fn (reference corr.py:174-189, :220)
     without materialising its input: frames (NF,H,W,C) half channel-last, ii / jj (E) int64, packed from
-    pack_offset_conv.  Returns (E, Cout, H, W) fp32."""
+    pack_offset_conv.  frames_lo: optional second half part of the input (input = frames + frames_lo, same shape).
+    Returns (E, Cout, H, W) fp32."""
     wpack, bias, Cout, C = packed
     _check_dtype(frames, "frames", torch.float16)
+    if frames_lo is not None:
+        _check_dtype(frames_lo, "frames_lo", torch.float16)
+        if frames_lo.shape != frames.shape:
+            raise RuntimeError("offset_conv_frames: frames_lo must have the shape of frames")
     _check_dtype(ii, "ii", torch.int64)
     _check_dtype(jj, "jj", torch.int64)
     NF, H, W, Cf = frames.shape
@@ -476,8 +481,8 @@ def offset_conv_frames(frames, ii, jj, packed):
     if E == 0:
         return out
     with torch.cuda.device(frames.device):
-        rc = _lib.load().lgu_offset_conv_frames_h16(_ptr(frames), _ptr(ii), _ptr(jj), _ptr(wpack), _ptr(bias), _ptr(out), E, H, W, C,
-                                                    Cout, _stream(frames))
+        rc = _lib.load().lgu_offset_conv_frames_h16(_ptr(frames), _ptr(frames_lo) if frames_lo is not None else None, _ptr(ii),
+                                                    _ptr(jj), _ptr(wpack), _ptr(bias), _ptr(out), E, H, W, C, Cout, _stream(frames))
     _lib.check(rc, "offset_conv_frames")
     return out
 

@@ -865,6 +865,18 @@ def test_offset_head_on_the_matrix_cores_equals_the_fp32_convolution(lgu, cfg):
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 1e-5 * scale
     assert float((got.double() - want64).abs().max()) <= 4 * max(float((want.double() - want64).abs().max()), 1e-7 * scale)
+    if H < 2 or W < 2:
+        return
+    # two-part input (the residual head, corr.py:219-220): 2 x 2 averages of the frames need up to 24 bits
+    with torch.no_grad():
+        pooled4 = torch.nn.functional.avg_pool2d(feats, kernel_size=2, stride=2)     # what the reference feeds ofs_residual
+        want2 = conv(pooled4)
+        pl_ = torch.nn.functional.avg_pool2d(frames.permute(0, 3, 1, 2).float(), kernel_size=2, stride=2).permute(0, 2, 3, 1).contiguous()
+        hi = pl_.half()
+        lo = (pl_ - hi.float()).half()
+        got2 = lgu.ops.offset_conv_frames(hi, ii, jj, packed, frames_lo=lo)
+    assert tuple(got2.shape) == tuple(want2.shape)
+    assert float((got2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
 def test_altcorrblock_offsets_from_frames_equal_the_general_composition(lgu, monkeypatch):
