@@ -147,6 +147,11 @@ int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge
                                     int L, int E, int H1, int W1, const int* H2, const int* W2,
                                     int radius, int enc_n, int flags, void* stream);
 
+/* The uncertainty mask of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:203-207) applied in place:
+ *   probe (E, T, H*W): the T = 9 plain level-1 samples of every pixel (altcorr_forward, radius 1);
+ *   offset (E, H*W, C) IN/OUT: offset[e][p][:] *= sigmoid(unbiased variance of probe[e][:][p]). */
+int lgu_probe_mask_scale_f32(const float* probe, float* offset, int E, int HW, int T, int C, void* stream);
+
 /* The level-0 offset head of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:174-189, :220:
  * ofsMap(cat(fmap[ii] * 4, fmap[jj] * 4).float()), a Conv2d(2C, Cout, 3, padding=1) evaluated in fp32) straight from the
  * stored half frame buffers, on the half matrix cores with fp32-accurate weights:

@@ -455,9 +455,13 @@ class AltCorrBlock:
                 iic, jjc = ii.contiguous(), jj.contiguous()
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
                 probe = ops.lowmem_pyramid_forward_mixed(frames[0], [frames[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1)
-                probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
-                mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
-                self.offset[1] = self.offset[1] * mask
+                o1 = self.offset[1]
+                if o1.dtype == torch.float32 and o1.is_contiguous() and not o1.requires_grad:
+                    ops.probe_mask_scale_(probe, o1)   # variance, sigmoid and the scaling in one pass, in place
+                else:
+                    probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
+                    mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
+                    self.offset[1] = self.offset[1] * mask
                 offs = [None if zero_level[i] else self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
                         for i in range(self.num_levels)]
                 fused = ops.lowmem_pyramid_forward_mixed(frames[0], frames, c0, offs, self.radius, ii=iic, jj=jjc)

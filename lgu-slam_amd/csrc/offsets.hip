@@ -149,9 +149,45 @@ __global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffP
   }
 }
 
+// offset[1] *= sigmoid(var(probe)) of AltCorrBlock.corr_fn (reference corr.py:203-207): probe (E, T, H, W) holds the T = 9
+// plain level-1 samples of every pixel, the variance is the unbiased one over them (torch.var default), the mask scales
+// the pixel's C offset values.  One workgroup = 32 pixels: 32 threads form the masks, all threads scale 32 x C floats.
+__global__ __launch_bounds__(OF_THREADS) void probe_mask_scale_kernel(const float* __restrict__ probe, float* __restrict__ offset,
+                                                                      int HW, int T, int C) {
+  __shared__ float mask[OF_TP];
+  const int e = blockIdx.y, pix0 = blockIdx.x * OF_TP;
+  if (threadIdx.x < OF_TP && pix0 + threadIdx.x < HW) {
+    const float* pp = probe + (size_t)e * T * HW + pix0 + threadIdx.x;
+    float mean = 0.0f;
+    for (int t = 0; t < T; t++) mean += pp[(size_t)t * HW];
+    mean /= (float)T;
+    float ss = 0.0f;
+    for (int t = 0; t < T; t++) {
+      const float d = pp[(size_t)t * HW] - mean;
+      ss += d * d;
+    }
+    const float var = ss / (float)(T - 1);
+    mask[threadIdx.x] = 1.0f / (1.0f + expf(-var));
+  }
+  __syncthreads();
+  const int npx = HW - pix0 < OF_TP ? HW - pix0 : OF_TP;
+  float* const o = offset + ((size_t)e * HW + pix0) * C;
+  for (int idx = threadIdx.x; idx < npx * C; idx += OF_THREADS) o[idx] *= mask[idx / C];
+}
+
 }  // namespace lgu
 
 extern "C" {
+
+int lgu_probe_mask_scale_f32(const float* probe, float* offset, int E, int HW, int T, int C, void* stream) {
+  using namespace lgu;
+  if (!probe || !offset || E < 0 || HW < 1 || T < 2 || C < 1) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  if (E > 65535) return LGU_E_UNSUPPORTED;
+  hipLaunchKernelGGL(probe_mask_scale_kernel, dim3((HW + OF_TP - 1) / OF_TP, E), dim3(OF_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), probe, offset, HW, T, C);
+  return launch_status();
+}
 
 long long lgu_offsets_finalize_scratch_bytes(int E) {
   return E < 0 ? 0 : (long long)E * lgu::OF_CHUNKS * 4 * (long long)sizeof(double);

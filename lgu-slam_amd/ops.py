@@ -440,6 +440,21 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+def probe_mask_scale_(probe, offset):
+    """offset *= sigmoid(var(probe over its taps)) in place (reference corr.py:203-207): probe (E,1,T,H,W) or (E,T,H,W)
+    fp32 from altcorr_forward / the fused probe launch, offset (E,H,W,C) fp32."""
+    _check(probe, "probe", offset, "offset")
+    E, H, W, C = offset.shape
+    T = probe.numel() // max(E * H * W, 1)
+    if probe.numel() != E * T * H * W or T < 2:
+        raise RuntimeError("probe_mask_scale_: probe must hold T >= 2 samples per pixel of offset")
+    if E:
+        with torch.cuda.device(offset.device):
+            rc = _lib.load().lgu_probe_mask_scale_f32(_ptr(probe), _ptr(offset), E, H * W, T, C, _stream(offset))
+        _lib.check(rc, "probe_mask_scale")
+    return offset
+
+
 def pack_offset_conv(weight, bias, scale=4.0):
     """Operands of lgu_offset_conv_frames_h16 from a Conv2d(2C, Cout, 3, padding=1)'s parameters: the weight times
     `scale` (AltCorrBlock feeds the convolution 4 x the stored frames; a power of two, exact) split into two half parts

@@ -916,6 +916,18 @@ def test_altcorrblock_offsets_from_frames_equal_the_general_composition(lgu, mon
     assert float((out_fast - out_ref).abs().max()) <= 1e-4 * float(out_ref.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 7, 9), (1, 60, 80)])
+def test_probe_mask_scale_equals_the_torch_composition(lgu, shape):
+    """lgu_probe_mask_scale_f32 == offset * sigmoid(var(probe, unbiased)) of corr.py:203-207, to fp32 rounding."""
+    E, H, W = shape
+    torch.manual_seed(E + H)
+    probe = torch.randn(E, 1, 9, H, W, device="cuda") * 0.7
+    off = torch.randn(E, H, W, 98, device="cuda") * 2
+    want = off * torch.sigmoid(torch.var(probe.permute(0, 1, 3, 4, 2).contiguous().view(E, H, W, 3, 3), dim=[3, 4])).view(E, H, W, 1)
+    got = lgu.ops.probe_mask_scale_(probe, off.clone())
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]
