@@ -85,7 +85,8 @@ def finish_offsets(o0, o1_low, num_levels):
         # inference: standardisation, tanh, residual mix, upsampling and the channel-last transposition in one pass
         try:
             off0, off1 = ops.offsets_finalize(o0.contiguous(), o1_low.contiguous())
-            offsets = [off0, off1] + [torch.zeros_like(off0) for _ in range(2, num_levels)]
+            zeros = torch.zeros_like(off0) if num_levels > 2 else None   # one buffer for every structurally-zero level:
+            offsets = [off0, off1] + [zeros] * (num_levels - 2)            # they are never written (samplers get None)
             return offsets[:num_levels], ([False, False] + [True] * (num_levels - 2))[:num_levels]
         except _lib.UnsupportedShape:
             pass
