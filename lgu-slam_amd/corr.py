@@ -63,6 +63,17 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
 FUSED_OFFSETS = True   # False: the reference-shaped torch composition below also in inference (A/B and tests)
 
 
+def _zero_offsets(like, n):
+    """A structurally-zero offset level (reference corr.py:132-135) for n edges without n copies of it: one zero row
+    expanded over the edge dimension (stride 0).  The samplers never read or write these levels (they get NULL), and
+    CorrBlock.cat / __getitem__ re-expand instead of copying; `.contiguous()` materialises the zeros if somebody asks."""
+    return torch.zeros((1,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device).expand((n,) + tuple(like.shape[1:]))
+
+
+def _is_zero_expansion(t):
+    return t.dim() >= 1 and t.shape[0] > 0 and t.stride(0) == 0
+
+
 def generate_offsets(ofsMap, ofs_residual, feats, num_levels):
     """Learned sampling offsets (reference corr.py:117-135 / :217-235).
 
@@ -85,8 +96,7 @@ def finish_offsets(o0, o1_low, num_levels):
         # inference: standardisation, tanh, residual mix, upsampling and the channel-last transposition in one pass
         try:
             off0, off1 = ops.offsets_finalize(o0.contiguous(), o1_low.contiguous())
-            zeros = torch.zeros_like(off0) if num_levels > 2 else None   # one buffer for every structurally-zero level:
-            offsets = [off0, off1] + [zeros] * (num_levels - 2)            # they are never written (samplers get None)
+            offsets = [off0, off1] + [_zero_offsets(off0, off0.shape[0])] * (num_levels - 2)
             return offsets[:num_levels], ([False, False] + [True] * (num_levels - 2))[:num_levels]
         except _lib.UnsupportedShape:
             pass
@@ -316,7 +326,11 @@ class CorrBlock:
                 other._to_reference_layout()
             self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self._pyr, other._pyr)]
         for i in range(self.num_levels):
-            self.offset[i] = torch.cat([self.offset[i], other.offset[i]], 0)
+            a, b = self.offset[i], other.offset[i]
+            if self._zero_level[i] and other._zero_level[i] and _is_zero_expansion(a) and _is_zero_expansion(b):
+                self.offset[i] = _zero_offsets(a, a.shape[0] + b.shape[0])   # still zero: nothing to copy
+            else:
+                self.offset[i] = torch.cat([a, b], 0)
             self._zero_level[i] = self._zero_level[i] and other._zero_level[i]
         return self
 
@@ -330,10 +344,17 @@ class CorrBlock:
             self._free = self._free + [sl for sl in self._slot_list if sl not in kept]
             self._slot_list = new_list
             self._slots_dev = None
+            # the kept positions are known on the host now: index the offsets with them (a boolean mask would cost one
+            # device -> host round trip per level)
+            index = torch.tensor(keep, dtype=torch.long, device=self._store[0].device)
         else:
             self.corr_pyramid = [v[index] for v in self._pyr]
         for i in range(self.num_levels):
-            self.offset[i] = self.offset[i][index]
+            o = self.offset[i]
+            if self._zero_level[i] and _is_zero_expansion(o) and index.dtype == torch.long and index.dim() == 1:
+                self.offset[i] = _zero_offsets(o, index.shape[0])
+            else:
+                self.offset[i] = o[index]
         return self
 
     @staticmethod
