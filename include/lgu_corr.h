@@ -147,6 +147,13 @@ int lgu_defcorr_pyramid_enc_fwd_f32(const float* const* volumes, const int* edge
                                     int L, int E, int H1, int W1, const int* H2, const int* W2,
                                     int radius, int enc_n, int flags, void* stream);
 
+/* Tail of GaussianMask.gaussian_parameters (reference droid_slam/gaussianMask_cuda.py:69-83) after the two linear heads:
+ *   mean_ofs, cov_raw (E, H*W, 2) fp32 or half (is_half: the heads ran under autocast; steps rounded to half like the
+ *   framework's half kernels);  mean (E,H,W,2) fp32 = pixel grid (x, y) + mean_ofs;  cov (E,H,W,2) fp32 =
+ *   sigmoid(per-sample standardised cov_raw) * 5 + 0.05;  det (E, H*W) = cov.x * cov.y in the input's dtype. */
+int lgu_gaussian_params(const void* mean_ofs, const void* cov_raw, float* mean, float* cov, void* det,
+                        int E, int H, int W, int is_half, float eps, void* stream);
+
 /* The uncertainty mask of AltCorrBlock.corr_fn (reference droid_slam/modules/corr.py:203-207) applied in place:
  *   probe (E, T, H*W): the T = 9 plain level-1 samples of every pixel (altcorr_forward, radius 1);
  *   offset (E, H*W, C) IN/OUT: offset[e][p][:] *= sigmoid(unbiased variance of probe[e][:][p]). */

@@ -175,9 +175,86 @@ __global__ __launch_bounds__(OF_THREADS) void probe_mask_scale_kernel(const floa
   for (int idx = threadIdx.x; idx < npx * C; idx += OF_THREADS) o[idx] *= mask[idx / C];
 }
 
+// Tail of GaussianMask.gaussian_parameters (reference droid_slam/gaussianMask_cuda.py:69-83) after the two 16 -> 2 linear
+// heads: cov = sigmoid(per-sample standardised covMap output) * 5 + 0.05, det = cov.x * cov.y, mean = pixel grid +
+// meanMap output — ~12 tiny launches (two of them one-output-per-sample reductions) in one: a workgroup per sample
+// sums its H*W*2 values (fp64, fixed order), then finishes its pixels.  HALF: the heads ran under autocast; every step is
+// rounded to half as the framework's half kernels do, cov is widened at the end (.float()), det stays half, and the mean
+// is the fp32 sum of the fp32 grid and the half head output (type promotion) — bit for bit the torch composition unless
+// a statistic lands across a half rounding boundary.
+template <bool HALF>
+__global__ __launch_bounds__(OF_THREADS) void ga_params_kernel(const void* __restrict__ mean_ofs, const void* __restrict__ cov_raw,
+                                                               float* __restrict__ mean, float* __restrict__ cov,
+                                                               void* __restrict__ det, int H, int W, float eps) {
+  const int e = blockIdx.x, HW = H * W, n = HW * 2;
+  const size_t base = (size_t)e * n;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < n; i += OF_THREADS) {
+    const double v = of_load<HALF>(cov_raw, base + i);
+    s += v; q += v * v;
+  }
+  __shared__ double red[OF_THREADS / kWave][2];
+  __shared__ float stat[2];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, kWave); q += __shfl_xor(q, m, kWave); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ts = 0.0, tq = 0.0;
+    for (int k = 0; k < OF_THREADS / kWave; k++) { ts += red[k][0]; tq += red[k][1]; }
+    const double mu = ts / n;
+    double var = tq / n - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    if (HALF) {
+      stat[0] = of_rh((float)mu);
+      stat[1] = of_rh(sqrtf(of_rh(of_rh((float)var) + eps)));
+    } else {
+      stat[0] = (float)mu;
+      stat[1] = sqrtf((float)var + eps);
+    }
+  }
+  __syncthreads();
+  const float mu = stat[0], sd = stat[1];
+  for (int pix = threadIdx.x; pix < HW; pix += OF_THREADS) {
+    const size_t o = base + (size_t)pix * 2;
+    float c[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const float x = of_load<HALF>(cov_raw, o + k);
+      if (HALF) {
+        const float z = of_rh(of_rh(x - mu) / sd);
+        const float sg = of_rh(1.0f / (1.0f + expf(-z)));
+        c[k] = of_rh(of_rh(sg * 5.0f) + 0.05f);
+      } else {
+        const float z = (x - mu) / sd;
+        c[k] = 1.0f / (1.0f + expf(-z)) * 5.0f + 0.05f;
+      }
+      cov[o + k] = c[k];
+    }
+    if (HALF) static_cast<_Float16*>(det)[(size_t)e * HW + pix] = (_Float16)(c[0] * c[1]);
+    else static_cast<float*>(det)[(size_t)e * HW + pix] = c[0] * c[1];
+    const int y = pix / W, xg = pix - y * W;
+    mean[o + 0] = (float)xg + of_load<HALF>(mean_ofs, o + 0);
+    mean[o + 1] = (float)y + of_load<HALF>(mean_ofs, o + 1);
+  }
+}
+
 }  // namespace lgu
 
 extern "C" {
+
+int lgu_gaussian_params(const void* mean_ofs, const void* cov_raw, float* mean, float* cov, void* det, int E, int H, int W,
+                        int is_half, float eps, void* stream) {
+  using namespace lgu;
+  if (!mean_ofs || !cov_raw || !mean || !cov || !det || E < 0 || H < 1 || W < 1) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (is_half)
+    hipLaunchKernelGGL(ga_params_kernel<true>, dim3(E), dim3(OF_THREADS), 0, st, mean_ofs, cov_raw, mean, cov, det, H, W, eps);
+  else
+    hipLaunchKernelGGL(ga_params_kernel<false>, dim3(E), dim3(OF_THREADS), 0, st, mean_ofs, cov_raw, mean, cov, det, H, W, eps);
+  return launch_status();
+}
 
 int lgu_probe_mask_scale_f32(const float* probe, float* offset, int E, int HW, int T, int C, void* stream) {
   using namespace lgu;

@@ -36,6 +36,9 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
     return (x - mean) / std
 
 
+FUSED_PARAMS = True   # False: the torch composition of gaussian_parameters also in inference (A/B and tests)
+
+
 class GaussianMask(nn.Module):
     """Predicts a mean (grid + learned shift) and a diagonal covariance per source pixel
     from the concatenated feature pair and re-weights the volume with it
@@ -63,7 +66,13 @@ class GaussianMask(nn.Module):
         b, h, w, _ = x.shape
         tt = self.mapA(x)
         mean_ofs = self.meanMap(tt).view(b, h, w, 2)
-        cov = per_Corr_Normalization(self.covMap(tt).view(b, h * w, 2), [1, 2])
+        cov_raw = self.covMap(tt).view(b, h * w, 2)
+        if (FUSED_PARAMS and cov_raw.is_cuda and cov_raw.dtype in (torch.float32, torch.float16)
+                and mean_ofs.dtype == cov_raw.dtype and not (torch.is_grad_enabled() and cov_raw.requires_grad)
+                and self.coord.shape[:2] == (h, w)):
+            # inference: everything below in one launch, with torch's arithmetic (incl. the half roundings under autocast)
+            return ops.gaussian_params(mean_ofs.contiguous(), cov_raw.contiguous(), h, w)
+        cov = per_Corr_Normalization(cov_raw, [1, 2])
         cov = torch.sigmoid(cov) * 5 + 0.05
         det = cov[:, :, 0] * cov[:, :, 1]
         cov = cov.view(b, h, w, 2).float()

@@ -440,6 +440,29 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+def gaussian_params(mean_ofs, cov_raw, h, w, eps=1e-5):
+    """Tail of GaussianMask.gaussian_parameters after the two linear heads (reference gaussianMask_cuda.py:69-83) in one
+    launch: mean_ofs, cov_raw (E, h*w, 2)-shaped, both fp32 or both half.  Returns mean (E,h,w,2) fp32, cov (E,h,w,2) fp32,
+    det (E, h*w) in the input dtype."""
+    if mean_ofs.dtype not in (torch.float32, torch.float16) or cov_raw.dtype != mean_ofs.dtype:
+        raise RuntimeError("gaussian_params: fp32 or half inputs of one dtype")
+    for t, nm in ((mean_ofs, "mean_ofs"), (cov_raw, "cov_raw")):
+        if not (t.is_cuda and t.is_contiguous()) or t.numel() % (h * w * 2) != 0:
+            raise RuntimeError("%s must be a contiguous CUDA tensor of (E, h*w, 2) elements" % nm)
+    E = mean_ofs.numel() // (h * w * 2)
+    if cov_raw.numel() != mean_ofs.numel():
+        raise RuntimeError("gaussian_params: mean_ofs and cov_raw differ in size")
+    mean = torch.empty((E, h, w, 2), dtype=torch.float32, device=mean_ofs.device)
+    cov = torch.empty_like(mean)
+    det = torch.empty((E, h * w), dtype=mean_ofs.dtype, device=mean_ofs.device)
+    if E:
+        with torch.cuda.device(mean.device):
+            rc = _lib.load().lgu_gaussian_params(_ptr(mean_ofs), _ptr(cov_raw), _ptr(mean), _ptr(cov), _ptr(det), E, h, w,
+                                                 1 if mean_ofs.dtype == torch.float16 else 0, float(eps), _stream(mean))
+        _lib.check(rc, "gaussian_params")
+    return mean, cov, det
+
+
 def probe_mask_scale_(probe, offset):
     """offset *= sigmoid(var(probe over its taps)) in place (reference corr.py:203-207): probe (E,1,T,H,W) or (E,T,H,W)
     fp32 from altcorr_forward / the fused probe launch, offset (E,H,W,C) fp32."""

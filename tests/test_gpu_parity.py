@@ -928,6 +928,50 @@ def test_probe_mask_scale_equals_the_torch_composition(lgu, shape):
     assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("shape", [(3, 24, 32), (2, 7, 9), (20, 48, 64)])
+def test_fused_gaussian_parameters_equal_the_torch_composition(lgu, shape, half):
+    """lgu_gaussian_params (the tail of GaussianMask.gaussian_parameters, gaussianMask_cuda.py:69-83, in one launch)
+    against the torch composition on the same head outputs: fp32 <= 2e-6 relative (statistics differ in summation
+    order); half (autocast) bit for bit unless a statistic lands across a half rounding boundary (then one half ulp of
+    the covariance, <= 2^-8 at 5)."""
+    from lgu_slam_amd.gaussian_mask import per_Corr_Normalization
+    E, h, w = shape
+    torch.manual_seed(E * 7 + h)
+    dt = torch.float16 if half else torch.float32
+    mean_ofs = (torch.randn(E, h, w, 2, device="cuda") * 0.7).to(dt)
+    cov_raw = (torch.randn(E, h * w, 2, device="cuda") * 1.3 + 0.2).to(dt)
+    cov = per_Corr_Normalization(cov_raw, [1, 2])
+    cov = torch.sigmoid(cov) * 5 + 0.05
+    det_w = cov[:, :, 0] * cov[:, :, 1]
+    cov_w = cov.view(E, h, w, 2).float()
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda").float(), torch.arange(w, device="cuda").float(), indexing="ij")
+    mean_w = torch.stack([xs, ys], dim=-1).expand(E, h, w, 2) + mean_ofs
+    mean, cov_g, det = lgu.ops.gaussian_params(mean_ofs, cov_raw, h, w)
+    assert mean.dtype == torch.float32 and cov_g.dtype == torch.float32 and det.dtype == dt and tuple(det.shape) == (E, h * w)
+    assert torch.equal(mean, mean_w.float())
+    if half:
+        assert float((cov_g - cov_w).abs().max()) <= 2.0 ** -8
+        assert float((det.float() - det_w.float()).abs().max()) <= 2.0 ** -5
+        assert float((cov_g != cov_w).float().mean()) <= 0.02   # bit-identical but for boundary cases
+    else:
+        assert float((cov_g - cov_w).abs().max()) <= 2e-6 * 5.05
+        assert float((det - det_w).abs().max()) <= 4e-6 * 25.5
+    # the module takes the fused route in inference and the composition under grad
+    GA = lgu.GaussianMask(h, w).cuda()
+    x = torch.randn(E, h, w, 256, device="cuda")
+    with torch.no_grad():
+        m1, c1, d1 = GA.gaussian_parameters(x)
+    import lgu_slam_amd.gaussian_mask as gm
+    gm.FUSED_PARAMS = False
+    try:
+        with torch.no_grad():
+            m2, c2, d2 = GA.gaussian_parameters(x)
+    finally:
+        gm.FUSED_PARAMS = True
+    assert float((m1 - m2).abs().max()) <= 1e-5 and float((c1 - c2).abs().max()) <= 2e-5 and tuple(d1.shape) == tuple(d2.shape)
+
+
 def test_tiled_layout_rejects_what_it_does_not_serve(lgu):
     v = [torch.randn(1, 8, 16, 8, 16, device="cuda"), torch.randn(1, 8, 16, 4, 8, device="cuda")]
     tv = [lgu.ops.volume_retile(x) for x in v]
