@@ -331,6 +331,13 @@ int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* 
 int lgu_ba_ev_f32(const float* E, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream);
 int lgu_ba_evt_f32(const float* E, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream);
 int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double lm, double ep, void* stream);
+/* lgu_ba_assemble_f64: the four scatter sums of one iteration, their zero-fills and the blocked -> dense permutation in one
+ * launch: block d = bi * P + bj of the system = sum of Hs rows [hptr[d], hptr[d+1]) of hidx - sum of S rows (sptr, sidx;
+ * S may be NULL: motion only), written to Ad (6P x 6P row-major, double); b (6P) likewise from vs / sv.  CSR tables cover
+ * all P*P (resp. P) destinations.  Per-entry arithmetic and summation order are those of lgu_ba_scatter_sum_f64. */
+int lgu_ba_assemble_f64(const float* Hs, const long long* hptr, const long long* hidx, const float* S, const long long* sptr,
+                        const long long* sidx, const float* vs, const long long* vptr, const long long* vidx, const float* sv,
+                        const long long* svptr, const long long* svidx, double* Ad, double* b, int P, void* stream);
 int lgu_ba_pose_retr_f32(float* poses, const float* dx, int t0, int t1, void* stream);
 int lgu_ba_disp_retr_f32(float* disps, const float* dz, const long long* inds, int n, int HW, void* stream);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lgu_ba_evt_f32": [_vp] * 4 + [_int] * 3 + [_vp],
     "lgu_ba_solve_f64": [_vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _vp],
     "lgu_ba_pose_retr_f32": [_vp] * 2 + [_int] * 2 + [_vp],
+    "lgu_ba_assemble_f64": [_vp] * 14 + [_int, _vp],
     "lgu_ba_disp_retr_f32": [_vp] * 3 + [_int] * 2 + [_vp],
     "lgu_altcorr_bwd_f32": [_vp] * 6 + [_int] * 8 + [_vp],
     "lgu_defcorr_pyramid_enc_fwd_f32": [ctypes.POINTER(_vp), _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _int, _int, _int,

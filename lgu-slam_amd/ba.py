@@ -85,6 +85,17 @@ def _solve(A, b, lm, ep):
     return torch.cholesky_solve(b[:, None], chol)[:, 0]
 
 
+def _csr(dest, ndst, dev):
+    """Rows grouped by destination (ascending row inside a group) as CSR over ALL ndst destinations: (ptr, idx) on dev.
+    Rows with a destination outside [0, ndst) are dropped."""
+    dest = np.asarray(dest, dtype=np.int64)
+    rows = np.nonzero((dest >= 0) & (dest < ndst))[0]
+    order = rows[np.argsort(dest[rows], kind="stable")]
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(dest[order], minlength=ndst))]).astype(np.int64)
+    idx = np.ascontiguousarray(order if len(order) else [0], dtype=np.int64)
+    return torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+
+
 class _Plan:
     """Everything of a BA call that depends only on the graph (ii, jj, t0, t1, motion_only): the index tables of the
     deterministic assembly, of the accumulations and of the Schur pair enumeration, resident on the device."""
@@ -101,8 +112,9 @@ class _Plan:
         # block indices of the pose-pose system; blocks of poses before t0 are dropped (update_lhs / update_rhs)
         bi_h = np.concatenate([ii_h, ii_h, jj_h, jj_h]) - t0
         bj_h = np.concatenate([ii_h, jj_h, ii_h, jj_h]) - t0
-        self.asm_H = _ScatterSum(lib, np.where((bi_h >= 0) & (bj_h >= 0), bi_h * P + bj_h, -1), dev)
-        self.asm_v = _ScatterSum(lib, np.concatenate([ii_h, jj_h]) - t0, dev)
+        self.csr_H = _csr(np.where((bi_h >= 0) & (bj_h >= 0) & (bi_h < P) & (bj_h < P), bi_h * P + bj_h, -1), P * P, dev)
+        self.csr_v = _csr(np.concatenate([ii_h, jj_h]) - t0, P, dev)
+        self.csr_S = self.csr_sv = None
         if motion_only:
             return
         # schur_block's pair enumeration (:1260-1290): E entries n, m meeting in the same depth frame
@@ -121,8 +133,8 @@ class _Plan:
         else:
             a_n = c_n = k_n = np.zeros(1, np.int64)
         self.trip_t = torch.from_numpy(np.ascontiguousarray(np.stack([a_n, c_n, k_n], 1))).to(dev)
-        self.asm_S = _ScatterSum(lib, (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0) if self.have_pairs else np.zeros(0, np.int64), dev)
-        self.asm_sv = _ScatterSum(lib, jj_exp_h - t0, dev)
+        self.csr_S = _csr((jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0), P * P, dev) if self.have_pairs else None
+        self.csr_sv = _csr(jj_exp_h - t0, P, dev)
         self.jpose = torch.from_numpy(jj_exp_h - t0).to(dev).contiguous()
         self.acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)
         self.acc_ii_ts = _Accum(lib, ii_h, ts_h, dev)
@@ -157,9 +169,9 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
     P = t1 - t0
     f32, f64 = torch.float32, torch.float64
     st = _stream(poses)
-    asm_H, asm_v, kx, kk = pl.asm_H, pl.asm_v, pl.kx, pl.kk
+    kx, kk = pl.kx, pl.kk
     if not motion_only:
-        have_pairs, trip_t, asm_S, asm_sv, jpose = pl.have_pairs, pl.trip_t, pl.asm_S, pl.asm_sv, pl.jpose
+        have_pairs, trip_t, jpose = pl.have_pairs, pl.trip_t, pl.jpose
         acc_ii_kx, acc_ii_ts, acc_exp_kx = pl.acc_ii_kx, pl.acc_ii_ts, pl.acc_exp_kx
         K = pl.K
         Q = torch.empty((K, HW), dtype=f32, device=dev)
@@ -179,24 +191,27 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
                                         _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
                                         st),
                    "ba build")
-        A = torch.zeros((P * P, 36), dtype=f64, device=dev)
-        asm_H(Hs.view(-1, 36), A, 1.0, st)
-        b = torch.zeros((P, 6), dtype=f64, device=dev)
-        asm_v(vs.view(-1, 6), b, 1.0, st)
+        S = sv = None
         if not motion_only:
             _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
                                                    _ptr(disps_sens), _ptr(eta_v), eta_v.shape[0], _ptr(Q), _ptr(w), K, HW, st),
                        "ba depth system")                                                          # :1394-1398
             acc_ii_ts(Eii.view(E, 6 * HW), st, out=Eall[:P].view(P, 6 * HW))             # :1400-1401
             nE = P + E
-            S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
             if have_pairs:
+                S = torch.empty((trip_t.shape[0], 6, 6), dtype=f32, device=dev)
                 _lib.check(lib.lgu_ba_eet_f32(_ptr(Eall), _ptr(Q), _ptr(trip_t), _ptr(S), trip_t.shape[0], HW, st), "ba EEt")
-                asm_S(S.view(-1, 36), A, -1.0, st)
             sv = torch.empty((nE, 6), dtype=f32, device=dev)
             _lib.check(lib.lgu_ba_ev_f32(_ptr(Eall), _ptr(Q), _ptr(w), _ptr(kk), _ptr(sv), nE, HW, st), "ba Ev")
-            asm_sv(sv, b, -1.0, st)
-        Ad = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
+        # the reduced camera system: H - S and v - sv summed per block in fixed order (double), dense layout, one launch
+        Ad = torch.empty((6 * P, 6 * P), dtype=f64, device=dev)
+        b = torch.empty((P, 6), dtype=f64, device=dev)
+        cS, cs = pl.csr_S if S is not None else None, pl.csr_sv if sv is not None else None
+        _lib.check(lib.lgu_ba_assemble_f64(_ptr(Hs), _ptr(pl.csr_H[0]), _ptr(pl.csr_H[1]),
+                                           _ptr(S) if S is not None else None, _ptr(cS[0]) if cS else None, _ptr(cS[1]) if cS else None,
+                                           _ptr(vs), _ptr(pl.csr_v[0]), _ptr(pl.csr_v[1]),
+                                           _ptr(sv) if sv is not None else None, _ptr(cs[0]) if cs else None, _ptr(cs[1]) if cs else None,
+                                           _ptr(Ad), _ptr(b), P, st), "ba assembly")
         dx = torch.empty((P, 6), dtype=f32, device=dev)
         rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
         if rc == _lib.LGU_E_UNSUPPORTED:   # more than 21 poses in the window: library Cholesky on the device

@@ -277,6 +277,47 @@ __global__ __launch_bounds__(BA_THREADS) void ba_scatter_sum_kernel(const float*
   out[(size_t)dst[j] * D + k] += sign * acc;
 }
 
+// ---- the whole reduced camera system in one launch: every 6 x 6 block (and 6-vector) = (sum of its rows of the first
+// source) - (sum of its rows of the second source), each sum in double in table order, written in the dense (6P x 6P)
+// row-major form the solver takes.  Replaces two zero-fills, four scatter-sum launches and a permuting copy; the
+// arithmetic per entry is the same ((0 + 1 * a) + (-1) * c), so the bits are too.  CSR tables over ALL destinations.
+__global__ __launch_bounds__(BA_THREADS) void ba_assemble_kernel(const float* __restrict__ Hs, const long long* __restrict__ hptr,
+                                                                 const long long* __restrict__ hidx, const float* __restrict__ S,
+                                                                 const long long* __restrict__ sptr, const long long* __restrict__ sidx,
+                                                                 const float* __restrict__ vs, const long long* __restrict__ vptr,
+                                                                 const long long* __restrict__ vidx, const float* __restrict__ sv,
+                                                                 const long long* __restrict__ svptr, const long long* __restrict__ svidx,
+                                                                 double* __restrict__ Ad, double* __restrict__ b, int P) {
+  const long long t = (long long)blockIdx.x * BA_THREADS + threadIdx.x;
+  const long long nA = (long long)P * P * 36;
+  if (t < nA) {
+    const int d = (int)(t / 36), k = (int)(t - (long long)d * 36);
+    double a = 0.0;
+    for (long long i = hptr[d]; i < hptr[d + 1]; i++) a += (double)Hs[(size_t)hidx[i] * 36 + k];
+    double out = 0.0;
+    if (hptr[d + 1] > hptr[d]) out += 1.0 * a;
+    if (S) {
+      double c = 0.0;
+      for (long long i = sptr[d]; i < sptr[d + 1]; i++) c += (double)S[(size_t)sidx[i] * 36 + k];
+      if (sptr[d + 1] > sptr[d]) out += -1.0 * c;
+    }
+    const int bi = d / P, bj = d - bi * P, r = k / 6, cidx = k - r * 6;
+    Ad[((size_t)bi * 6 + r) * (6 * P) + bj * 6 + cidx] = out;
+  } else if (t < nA + (long long)P * 6) {
+    const int u = (int)(t - nA), d = u / 6, k = u - d * 6;
+    double a = 0.0;
+    for (long long i = vptr[d]; i < vptr[d + 1]; i++) a += (double)vs[(size_t)vidx[i] * 6 + k];
+    double out = 0.0;
+    if (vptr[d + 1] > vptr[d]) out += 1.0 * a;
+    if (sv) {
+      double c = 0.0;
+      for (long long i = svptr[d]; i < svptr[d + 1]; i++) c += (double)sv[(size_t)svidx[i] * 6 + k];
+      if (svptr[d + 1] > svptr[d]) out += -1.0 * c;
+    }
+    b[u] = out;
+  }
+}
+
 // ---- S[b] = (E[ix] * Q[kx]) E[jx]^T over the pixels (:1001-1056) ----
 __global__ __launch_bounds__(BA_THREADS) void ba_eet_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
                                                             const long long* __restrict__ idx, float* __restrict__ S, int D) {
@@ -586,6 +627,18 @@ int lgu_ba_scatter_sum_f64(const float* inp, const long long* ptrs, const long l
   const unsigned grid = (unsigned)(((size_t)m * D + BA_THREADS - 1) / BA_THREADS);
   hipLaunchKernelGGL(ba_scatter_sum_kernel, dim3(grid), dim3(BA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), inp, ptrs, idxs,
                      dst, out, m, D, sign);
+  return launch_status();
+}
+
+int lgu_ba_assemble_f64(const float* Hs, const long long* hptr, const long long* hidx, const float* S, const long long* sptr,
+                        const long long* sidx, const float* vs, const long long* vptr, const long long* vidx, const float* sv,
+                        const long long* svptr, const long long* svidx, double* Ad, double* b, int P, void* stream) {
+  using namespace lgu;
+  if (!Hs || !hptr || !hidx || !vs || !vptr || !vidx || !Ad || !b || P < 1) return LGU_E_BADARG;
+  if ((S && (!sptr || !sidx)) || (sv && (!svptr || !svidx))) return LGU_E_BADARG;
+  const long long n = (long long)P * P * 36 + (long long)P * 6;
+  hipLaunchKernelGGL(ba_assemble_kernel, dim3((unsigned)((n + BA_THREADS - 1) / BA_THREADS)), dim3(BA_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), Hs, hptr, hidx, S, sptr, sidx, vs, vptr, vidx, sv, svptr, svidx, Ad, b, P);
   return launch_status();
 }
 

@@ -7,6 +7,8 @@ reprojections: zero residual => zero update, quadratic convergence of the reproj
 depths (which fails for a wrong Jacobian), motion-only mode, and the fixed-pose window [t0, t1).
 The HIP implementation (GPU tests below) is held to the oracle.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -207,6 +209,51 @@ def test_hip_ba_is_bit_reproducible(lgu):
         dx, dz = lgu.ba.ba(pd, dd, idv, sd, td, wd_, ed, iid, jjd, 1, len(p), 3, 1e-4, 0.1, False)
         outs.append((pd.clone(), dd.clone(), dx.clone(), dz.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("motion_only", [False, True])
+def test_fused_assembly_equals_the_scatter_sum_composition(lgu, motion_only):
+    """lgu_ba_assemble_f64 (the whole reduced camera system in one launch) == zero-fill + lgu_ba_scatter_sum_f64 of the H
+    blocks, minus that of the Schur blocks, + the blocked -> dense permutation, BIT FOR BIT (same per-entry arithmetic
+    and summation order), on the index tables of a real graph."""
+    from lgu_slam_amd import ba as B
+    rng, intr, poses, disps, ii, jj, targets = scene(31, N=9, H=6, W=8, span=3)
+    t0, t1 = 2, len(poses)
+    P, E = t1 - t0, len(ii)
+    lib = lgu._lib.load()
+    pl = B._Plan(lib, ii.astype(np.int64), jj.astype(np.int64), t0, t1, motion_only, torch.device("cuda"))
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    Hs = torch.randn(4 * E, 36, device="cuda", generator=g)
+    vs = torch.randn(2 * E, 6, device="cuda", generator=g)
+    ii_h, jj_h = ii.astype(np.int64), jj.astype(np.int64)
+    bi = np.concatenate([ii_h, ii_h, jj_h, jj_h]) - t0
+    bj = np.concatenate([ii_h, jj_h, ii_h, jj_h]) - t0
+    st = torch.cuda.current_stream().cuda_stream
+    A = torch.zeros(P * P, 36, dtype=torch.float64, device="cuda")
+    b = torch.zeros(P, 6, dtype=torch.float64, device="cuda")
+    B._ScatterSum(lib, np.where((bi >= 0) & (bj >= 0), bi * P + bj, -1), "cuda")(Hs, A, 1.0, st)
+    B._ScatterSum(lib, np.concatenate([ii_h, jj_h]) - t0, "cuda")(vs, b, 1.0, st)
+    S = sv = None
+    if not motion_only:
+        trip = pl.trip_t.cpu().numpy()
+        ts = np.arange(t0, t1)
+        jj_exp = np.concatenate([ts, jj_h])
+        S = torch.randn(trip.shape[0], 36, device="cuda", generator=g)
+        sv = torch.randn(P + E, 6, device="cuda", generator=g)
+        B._ScatterSum(lib, (jj_exp[trip[:, 0]] - t0) * P + (jj_exp[trip[:, 1]] - t0), "cuda")(S, A, -1.0, st)
+        B._ScatterSum(lib, jj_exp - t0, "cuda")(sv, b, -1.0, st)
+    want = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
+    Ad = torch.full((6 * P, 6 * P), 7.0, dtype=torch.float64, device="cuda")
+    bd = torch.full((P, 6), 7.0, dtype=torch.float64, device="cuda")
+    vp = lambda t_: ctypes.c_void_p(t_.data_ptr()) if t_ is not None else None
+    cS, cs = (pl.csr_S, pl.csr_sv) if not motion_only else (None, None)
+    rc = lib.lgu_ba_assemble_f64(vp(Hs), vp(pl.csr_H[0]), vp(pl.csr_H[1]), vp(S), vp(cS[0]) if cS else None, vp(cS[1]) if cS else None,
+                                 vp(vs), vp(pl.csr_v[0]), vp(pl.csr_v[1]), vp(sv), vp(cs[0]) if cs else None, vp(cs[1]) if cs else None,
+                                 vp(Ad), vp(bd), P, st)
+    assert rc == 0
+    assert torch.equal(Ad, want) and torch.equal(bd, b)
+    assert float(want.abs().max()) > 0
 
 
 @pytest.mark.gpu

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Driver for rocprofv3 runs of the dense BA at backend scale (200 keyframes of 60x80, 1970 edges, 2 iterations)."""
+"""Driver for rocprofv3 runs of the dense BA: backend scale by default (200 keyframes of 60x80, 1970 edges within 5
+frames, window [1, 200)), `frontend` as first argument for 12 keyframes of 48x64, edges within 3 frames, window [2, 12);
+2 iterations either way."""
 import os
 import sys
 import time
@@ -12,9 +14,10 @@ import lgu_slam_amd as lgu  # noqa: E402
 
 dev = "cuda"
 torch.manual_seed(0)
-N, h, w = 200, 60, 80
-ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= 5]
-jj_l = [j for i in range(N) for j in range(N) if i != j and abs(i - j) <= 5]
+FRONT = len(sys.argv) > 1 and sys.argv[1] == "frontend"
+N, h, w, span, T0 = (12, 48, 64, 3, 2) if FRONT else (200, 60, 80, 5, 1)
+ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= span]
+jj_l = [j for i in range(N) for j in range(N) if i != j and abs(i - j) <= span]
 ii, jj = torch.tensor(ii_l, device=dev), torch.tensor(jj_l, device=dev)
 poses = torch.zeros(N, 7, device=dev)
 poses[:, 6] = 1
@@ -26,9 +29,9 @@ tgt = torch.stack([xs, ys])[None].repeat(len(ii_l), 1, 1, 1) + torch.randn(len(i
 wgt = torch.rand(len(ii_l), 2, h, w, device=dev)
 eta = torch.full((N, h, w), 1e-3, device=dev)
 sens = torch.zeros_like(disps)
-for rep in range(3):
+for rep in range(12 if FRONT else 3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, ii, jj, 1, N, 2, 1e-4, 0.1, False)
+    lgu.ba.ba(poses.clone(), disps.clone(), intr, sens, tgt, wgt, eta, ii, jj, T0, N, 2, 1e-4, 0.1, False)
     torch.cuda.synchronize()
     print("ba call %d: %.2f ms" % (rep, (time.perf_counter() - t0) * 1e3))
