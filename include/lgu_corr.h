@@ -311,7 +311,7 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
  * lgu_ba_solve_f64        SparseBlock::solve (:1206-1231), which the reference runs on the CPU with Eigen: damping
  *                         diag += ep + lm*diag, blocked Cholesky and both triangular solves in one workgroup with the
  *                         matrix in LDS.  A (6P x 6P, row-major double, symmetric), b (6P) double; x (P,6) float; x = 0
- *                         if the damped matrix is not positive definite.  6P <= 126, otherwise LGU_E_UNSUPPORTED.
+ *                         if the damped matrix is not positive definite.  6P <= 192 (the matrix lives in LDS as a packed lower triangle), otherwise LGU_E_UNSUPPORTED.
  * lgu_ba_pose_retr_f32    pose_retr_kernel (:898-931): poses[k] <- exp(dx[k-t0]) * poses[k], k in [t0, t1).
  * lgu_ba_disp_retr_f32    disp_retr_kernel (:933-946): disps[inds[b]] += dz[b]. */
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,

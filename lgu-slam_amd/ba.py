@@ -214,7 +214,7 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
                                            _ptr(Ad), _ptr(b), P, st), "ba assembly")
         dx = torch.empty((P, 6), dtype=f32, device=dev)
         rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
-        if rc == _lib.LGU_E_UNSUPPORTED:   # more than 21 poses in the window: library Cholesky on the device
+        if rc == _lib.LGU_E_UNSUPPORTED:   # more than 32 poses in the window: library Cholesky on the device
             dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
         else:
             _lib.check(rc, "ba solve")

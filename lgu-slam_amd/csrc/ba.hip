@@ -442,22 +442,23 @@ __global__ __launch_bounds__(BA_THREADS) void ba_disp_retr_kernel(float* disps, 
 
 // ---- reduced camera system: damping + blocked Cholesky + solve in ONE workgroup (SparseBlock::solve :1206-1231) ----
 // A (n x n, n = 6 P, row-major double, symmetric) and b (n) stay untouched; x (P,6) float.  The matrix lives in LDS
-// (n <= 126: 127 KB), factorised by 6 x 6 block columns: diagonal block by one thread in registers, panel solve with
+// (packed lower triangle, n <= 192 = 32 poses: 148 KB), factorised by 6 x 6 block columns: diagonal block by one thread in registers, panel solve with
 // lanes over rows, trailing update with lanes over (row, column) pairs; then the two triangular solves by one wave.  Not positive
 // definite (a pivot <= 0 or not finite): x = 0, as the reference does when Eigen reports failure.
-constexpr int BA_SOLVE_MAXN = 126;
+constexpr int BA_SOLVE_MAXN = 192;
+#define LT(i, j) Ls[(((i) * ((i) + 1)) >> 1) + (j)]  // packed lower triangle, j <= i
 __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               float* __restrict__ x, int n, double lm, double ep) {
-  extern __shared__ double Ls[];  // [n][n + 1] lower triangle used, then [n] rhs
-  const int ld = n + 1;
-  double* const y = Ls + (size_t)n * ld;
+  extern __shared__ double Ls[];  // packed lower triangle n (n + 1) / 2, then [n] rhs
+  double* const y = Ls + (((size_t)n * (n + 1)) >> 1);
   int& bad = *reinterpret_cast<int*>(y + n);
   if (threadIdx.x == 0) bad = 0;
   for (int idx = threadIdx.x; idx < n * n; idx += BA_THREADS) {
     const int i = idx / n, j = idx - i * n;
+    if (j > i) continue;
     double v = A[idx];
     if (i == j) v += ep + lm * v;  // L.diagonal() += ep + lm * L.diagonal()
-    Ls[i * ld + j] = v;
+    LT(i, j) = v;
   }
   for (int i = threadIdx.x; i < n; i += BA_THREADS) y[i] = b[i];
   __syncthreads();
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) a[i][j] = Ls[(k0 + i) * ld + k0 + j];
+        for (int j = 0; j <= i; j++) a[i][j] = LT(k0 + i, k0 + j);
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         double d = a[k][k];
@@ -489,15 +490,15 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) Ls[(k0 + i) * ld + k0 + j] = a[i][j];
+        for (int j = 0; j <= i; j++) LT(k0 + i, k0 + j) = a[i][j];
     }
     __syncthreads();
     // panel: rows below the block solve L_ik L_kk^T = A_ik
     for (int i = k0 + 6 + threadIdx.x; i < n; i += BA_THREADS) {
       for (int k = k0; k < k0 + 6; k++) {
-        double v = Ls[i * ld + k];
-        for (int p = k0; p < k; p++) v -= Ls[i * ld + p] * Ls[k * ld + p];
-        Ls[i * ld + k] = v / Ls[k * ld + k];
+        double v = LT(i, k);
+        for (int p = k0; p < k; p++) v -= LT(i, p) * LT(k, p);
+        LT(i, k) = v / LT(k, k);
       }
     }
     __syncthreads();
@@ -508,41 +509,55 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
       if (j > i) continue;
       double v = 0.0;
 #pragma unroll
-      for (int p = 0; p < 6; p++) v += Ls[i * ld + k0 + p] * Ls[j * ld + k0 + p];
-      Ls[i * ld + j] -= v;
+      for (int p = 0; p < 6; p++) v += LT(i, k0 + p) * LT(j, k0 + p);
+      LT(i, j) -= v;
     }
     __syncthreads();
   }
-  // L y = b, L^T x = y by ONE wave, column by column: lane l holds entries l and l + 64 of the right-hand side
-  // (n <= 126), the pivot entry is broadcast with v_readlane and every lane updates its own entries — 2 n dependent
+  // L y = b, L^T x = y by ONE wave, column by column: lane l holds entries l, l + 64 and l + 128 of the right-hand side
+  // (n <= 192), the pivot entry is broadcast with v_readlane and every lane updates its own entries — 2 n dependent
   // steps of ~200 cycles instead of n^2 serial operations of one thread.  Forward: the subtractions reach every entry
   // in the order of the row-by-row loop (ascending column), so L y = b is bit-identical to it.
   if (threadIdx.x < kWave && !bad) {
     const int l = threadIdx.x;
-    double y0 = l < n ? y[l] : 0.0, y1 = l + kWave < n ? y[l + kWave] : 0.0;
+    double yv[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) yv[q] = l + q * kWave < n ? y[l + q * kWave] : 0.0;
     auto bcast = [](double v, int src) {
       const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
       const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
       return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     };
     for (int i = 0; i < n; i++) {  // forward
-      const double yi = bcast(i < kWave ? y0 : y1, i & (kWave - 1)) / Ls[i * ld + i];
-      if (l == (i & (kWave - 1))) { if (i < kWave) y0 = yi; else y1 = yi; }
-      if (l > i && l < n) y0 -= Ls[l * ld + i] * yi;
-      if (l + kWave > i && l + kWave < n) y1 -= Ls[(l + kWave) * ld + i] * yi;
+      const int qi = i >> 6, li = i & (kWave - 1);  // wave-uniform
+      const double piv = qi == 0 ? yv[0] : qi == 1 ? yv[1] : yv[2];
+      const double yi = bcast(piv, li) / LT(i, i);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int r = l + q * kWave;
+        if (q == qi && l == li) yv[q] = yi;
+        if (r > i && r < n) yv[q] -= LT(r, i) * yi;
+      }
     }
     for (int i = n - 1; i >= 0; i--) {  // backward: row i of L is column i of L^T
-      const double xi = bcast(i < kWave ? y0 : y1, i & (kWave - 1)) / Ls[i * ld + i];
-      if (l == (i & (kWave - 1))) { if (i < kWave) y0 = xi; else y1 = xi; }
-      if (l < i) y0 -= Ls[i * ld + l] * xi;
-      if (l + kWave < i) y1 -= Ls[i * ld + l + kWave] * xi;
+      const int qi = i >> 6, li = i & (kWave - 1);
+      const double piv = qi == 0 ? yv[0] : qi == 1 ? yv[1] : yv[2];
+      const double xi = bcast(piv, li) / LT(i, i);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int r = l + q * kWave;
+        if (q == qi && l == li) yv[q] = xi;
+        if (r < i) yv[q] -= LT(i, r) * xi;
+      }
     }
-    if (l < n) y[l] = y0;
-    if (l + kWave < n) y[l + kWave] = y1;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      if (l + q * kWave < n) y[l + q * kWave] = yv[q];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += BA_THREADS) x[i] = bad ? 0.0f : (float)y[i];
 }
+#undef LT
 
 }  // namespace lgu
 
@@ -561,7 +576,7 @@ int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double l
   if (!A || !b || !x || P < 1) return LGU_E_BADARG;
   const int n = 6 * P;
   if (n > BA_SOLVE_MAXN) return LGU_E_UNSUPPORTED;  // larger systems: the caller uses a library factorisation
-  const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + n + 1);
+  const size_t lds = sizeof(double) * ((((size_t)n * (n + 1)) >> 1) + n + 1);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -289,10 +289,10 @@ def test_hip_ba_plan_cache_follows_the_graph(lgu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P", [1, 3, 21])
+@pytest.mark.parametrize("P", [1, 3, 11, 21, 25, 32])
 def test_device_cholesky_solve_against_numpy(lgu, P):
-    """lgu_ba_solve_f64: (A + diag(ep + lm diag A)) x = b in one workgroup with the matrix in LDS (6P <= 126, the
-    frontend window), against numpy.linalg in double; a matrix that is not positive definite gives x = 0, as the
+    """lgu_ba_solve_f64: (A + diag(ep + lm diag A)) x = b in one workgroup with the matrix in LDS (packed lower triangle, 6P <= 192:
+    frontend windows of up to 32 keyframes), against numpy.linalg in double; a matrix that is not positive definite gives x = 0, as the
     reference's Eigen path does; larger systems are reported unsupported (the glue then uses a library factorisation)."""
     import ctypes
     rng = np.random.default_rng(100 + P)
@@ -322,8 +322,8 @@ def test_device_cholesky_solve_against_numpy(lgu, P):
     Abad[n // 2, n // 2] = -5.0 * np.abs(A).max()
     rc, got = solve(Abad)
     assert rc == 0 and not got.any()
-    if P == 21:
-        big = np.eye(6 * 22)
-        rc = lib.lgu_ba_solve_f64(ctypes.c_void_p(torch.from_numpy(big).cuda().data_ptr()), ctypes.c_void_p(torch.zeros(132, dtype=torch.float64, device="cuda").data_ptr()),
-                                  ctypes.c_void_p(torch.zeros(22, 6, device="cuda").data_ptr()), 22, lm, ep, None)
+    if P == 32:
+        big = torch.eye(6 * 33, dtype=torch.float64, device="cuda")
+        rc = lib.lgu_ba_solve_f64(ctypes.c_void_p(big.data_ptr()), ctypes.c_void_p(torch.zeros(198, dtype=torch.float64, device="cuda").data_ptr()),
+                                  ctypes.c_void_p(torch.zeros(33, 6, device="cuda").data_ptr()), 33, lm, ep, None)
         assert rc == lgu._lib.LGU_E_UNSUPPORTED

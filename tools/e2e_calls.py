@@ -93,6 +93,26 @@ with torch.no_grad():
         lgu.ba.ba(pbuf, dbuf, intr, sens, tgt, wgt, eta, iib, jjb, 2, N, 2, 1e-4, 0.1, False)
 
     res["ba: 12 keyframes 48x64, %d edges, 2 iterations (ms, wall incl. host bookkeeping)" % len(ii_l)] = wall(run_ba, iters=10, warm=2)
+    # the demo's frontend window (25 keyframes): the reduced system (150 x 150) still fits the single-workgroup LDS solver
+    N2 = 26
+    ii2 = [i for i in range(N2) for j in range(N2) if i != j and abs(i - j) <= 3]
+    jj2 = [j for i in range(N2) for j in range(N2) if i != j and abs(i - j) <= 3]
+    ii2t, jj2t = torch.tensor(ii2, device=dev), torch.tensor(jj2, device=dev)
+    poses2 = torch.zeros(N2, 7, device=dev)
+    poses2[:, 6] = 1
+    poses2[:, 0] = torch.arange(N2, device=dev) * 0.05
+    disps2 = 0.3 + 0.7 * torch.rand(N2, h, w, device=dev)
+    tgt2 = torch.stack([xs2, ys2])[None].repeat(len(ii2), 1, 1, 1) + torch.randn(len(ii2), 2, h, w, device=dev)
+    wgt2 = torch.rand(len(ii2), 2, h, w, device=dev)
+    eta2 = torch.full((N2, h, w), 1e-3, device=dev)
+    sens2 = torch.zeros_like(disps2)
+    pb2, db2 = poses2.clone(), disps2.clone()
+
+    def run_ba25():
+        pb2.copy_(poses2); db2.copy_(disps2)
+        lgu.ba.ba(pb2, db2, intr, sens2, tgt2, wgt2, eta2, ii2t, jj2t, 1, N2, 2, 1e-4, 0.1, False)
+
+    res["ba: 26 keyframes 48x64 (window of 25), %d edges, 2 iterations (ms, wall)" % len(ii2)] = wall(run_ba25, iters=10, warm=2)
     # backend-sized BA: 200 keyframes of 60x80, edges within 5 frames (1970 edges), window [1, 200), 2 iterations
     N, h, w = 200, 60, 80
     ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= 5]
