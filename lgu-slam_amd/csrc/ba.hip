@@ -446,21 +446,22 @@ __global__ __launch_bounds__(BA_THREADS) void ba_disp_retr_kernel(float* disps, 
 // lanes over rows, trailing update with lanes over (row, column) pairs; then the two triangular solves by one wave.  Not positive
 // definite (a pivot <= 0 or not finite): x = 0, as the reference does when Eigen reports failure.
 constexpr int BA_SOLVE_MAXN = 192;
+constexpr int BA_SOLVE_THREADS = 1024;  // one workgroup = the whole CU: 16 waves to hide the LDS latency of the updates
 #define LT(i, j) Ls[(((i) * ((i) + 1)) >> 1) + (j)]  // packed lower triangle, j <= i
-__global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __restrict__ A, const double* __restrict__ b,
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_kernel(const double* __restrict__ A, const double* __restrict__ b,
                                                               float* __restrict__ x, int n, double lm, double ep) {
   extern __shared__ double Ls[];  // packed lower triangle n (n + 1) / 2, then [n] rhs
   double* const y = Ls + (((size_t)n * (n + 1)) >> 1);
   int& bad = *reinterpret_cast<int*>(y + n);
   if (threadIdx.x == 0) bad = 0;
-  for (int idx = threadIdx.x; idx < n * n; idx += BA_THREADS) {
+  for (int idx = threadIdx.x; idx < n * n; idx += BA_SOLVE_THREADS) {
     const int i = idx / n, j = idx - i * n;
     if (j > i) continue;
     double v = A[idx];
     if (i == j) v += ep + lm * v;  // L.diagonal() += ep + lm * L.diagonal()
     LT(i, j) = v;
   }
-  for (int i = threadIdx.x; i < n; i += BA_THREADS) y[i] = b[i];
+  for (int i = threadIdx.x; i < n; i += BA_SOLVE_THREADS) y[i] = b[i];
   __syncthreads();
   const int nb = n / 6;
   for (int kb = 0; kb < nb; kb++) {
@@ -493,24 +494,59 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
         for (int j = 0; j <= i; j++) LT(k0 + i, k0 + j) = a[i][j];
     }
     __syncthreads();
-    // panel: rows below the block solve L_ik L_kk^T = A_ik
-    for (int i = k0 + 6 + threadIdx.x; i < n; i += BA_THREADS) {
-      for (int k = k0; k < k0 + 6; k++) {
-        double v = LT(i, k);
-        for (int p = k0; p < k; p++) v -= LT(i, p) * LT(k, p);
-        LT(i, k) = v / LT(k, k);
+    // panel: rows below the block solve L_ik L_kk^T = A_ik; the factor block and the row live in registers, so the six
+    // columns of a row are not a chain of LDS round trips.  (Factorising the block redundantly in every thread to save
+    // this barrier was measured and is slower: 1024 copies of the double-precision sqrt / divide sequences.)
+    if (k0 + 6 + (int)threadIdx.x < n) {
+      double a[6][6];
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) a[i][j] = LT(k0 + i, k0 + j);
+      for (int i = k0 + 6 + threadIdx.x; i < n; i += BA_SOLVE_THREADS) {
+        double r[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) r[k] = LT(i, k0 + k);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          double v = r[k];
+#pragma unroll
+          for (int p = 0; p < k; p++) v -= r[p] * a[k][p];
+          r[k] = v / a[k][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) LT(i, k0 + k) = r[k];
       }
     }
     __syncthreads();
-    // trailing update of the lower triangle: A_ij -= L_i,kb L_j,kb^T for j <= i, both below the block
-    const int m = n - (k0 + 6);
-    for (int idx = threadIdx.x; idx < m * m; idx += BA_THREADS) {
-      const int i = k0 + 6 + idx / m, j = k0 + 6 + idx % m;
-      if (j > i) continue;
-      double v = 0.0;
+    // trailing update of the lower triangle: A_ij -= L_i,kb L_j,kb^T for j <= i, both below the block.  2 x 2 entries
+    // per thread (24 LDS reads for 24 multiply-adds instead of 48); every entry's sum keeps the order p = 0..5.
+    const int m = n - (k0 + 6), T = (m + 1) >> 1;
+    for (int idx = threadIdx.x; idx < T * T; idx += BA_SOLVE_THREADS) {
+      const int ti = idx / T, tj = idx - ti * T;
+      if (tj > ti) continue;
+      const int i0 = k0 + 6 + 2 * ti, j0 = k0 + 6 + 2 * tj;
+      const bool i1v = i0 + 1 < n, j1v = j0 + 1 < n;
+      double li0[6], li1[6], lj0[6], lj1[6];
 #pragma unroll
-      for (int p = 0; p < 6; p++) v += LT(i, k0 + p) * LT(j, k0 + p);
-      LT(i, j) -= v;
+      for (int p = 0; p < 6; p++) {
+        li0[p] = LT(i0, k0 + p);
+        lj0[p] = LT(j0, k0 + p);
+        li1[p] = i1v ? LT(i0 + 1, k0 + p) : 0.0;
+        lj1[p] = j1v ? LT(j0 + 1, k0 + p) : 0.0;
+      }
+      double v00 = 0.0, v01 = 0.0, v10 = 0.0, v11 = 0.0;
+#pragma unroll
+      for (int p = 0; p < 6; p++) {
+        v00 += li0[p] * lj0[p];
+        v01 += li0[p] * lj1[p];
+        v10 += li1[p] * lj0[p];
+        v11 += li1[p] * lj1[p];
+      }
+      LT(i0, j0) -= v00;                                   // j0 <= i0 always
+      if (j1v && j0 + 1 <= i0) LT(i0, j0 + 1) -= v01;       // above the diagonal in a diagonal tile
+      if (i1v) LT(i0 + 1, j0) -= v10;
+      if (i1v && j1v) LT(i0 + 1, j0 + 1) -= v11;
     }
     __syncthreads();
   }
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_solve_kernel(const double* __re
       if (l + q * kWave < n) y[l + q * kWave] = yv[q];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += BA_THREADS) x[i] = bad ? 0.0f : (float)y[i];
+  for (int i = threadIdx.x; i < n; i += BA_SOLVE_THREADS) x[i] = bad ? 0.0f : (float)y[i];
 }
 #undef LT
 
@@ -582,7 +618,7 @@ int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double l
     hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_THREADS), lds, reinterpret_cast<hipStream_t>(stream), A, b, x, n, lm, ep);
+  hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds, reinterpret_cast<hipStream_t>(stream), A, b, x, n, lm, ep);
   return launch_status();
 }
 
