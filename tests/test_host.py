@@ -247,3 +247,38 @@ def test_corr_encoder_host_logic():
     with pytest.raises(RuntimeError):
         lgu.ops.DefcorrPyramidPlan.__init__(object.__new__(lgu.ops.DefcorrPyramidPlan), [], [], 3, out_format="nchw")
     assert lgu.CorrBlock.OUT_FORMAT == "planar" and set(lgu.ops.OUT_FORMATS) == {"planar", "nhwc", "nhwc_f16"}
+
+
+def test_offset_conv_weight_packing_host_logic():
+    """pack_offset_conv: hi + lo reproduces scale * W to 2^-21 relative, zero rows beyond Cout, and the MFMA fragment
+    order [tap][kstep][part][ntile][kg][nl][8] maps back to W[n = ntile*16 + nl][c = kstep*32 + kg*8 + t][tap]."""
+    import lgu_slam_amd as lgu
+    torch.manual_seed(3)
+    W = torch.randn(98, 256, 3, 3)
+    b = torch.randn(98)
+    wpack, bias, Cout, C = lgu.ops.pack_offset_conv(W, b, scale=4.0)
+    assert (Cout, C) == (98, 128) and tuple(wpack.shape) == (9, 8, 2, 7, 4, 16, 8) and wpack.dtype == torch.float16
+    assert bias.dtype == torch.float32 and torch.equal(bias, b)
+    rec = (wpack[:, :, 0].float() + wpack[:, :, 1].float())          # [tap][kstep][ntile][kg][nl][t]
+    rec = rec.permute(2, 4, 1, 3, 5, 0).reshape(112, 256, 9)        # [n][c][tap]
+    want = torch.zeros(112, 256, 9)
+    want[:98] = (W * 4.0).reshape(98, 256, 9)
+    assert float((rec - want).abs().max()) <= 2.0 ** -21 * float(want.abs().max())
+    assert float(rec[98:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        lgu.ops.pack_offset_conv(torch.randn(120, 256, 3, 3), torch.randn(120))
+    with pytest.raises(RuntimeError):
+        lgu.ops.pack_offset_conv(torch.randn(98, 256, 1, 1), b)
+
+
+def test_ba_assembly_tables_host_logic():
+    """ba._csr: rows grouped by destination (ascending row inside a group), CSR over ALL destinations, rows pointing
+    outside [0, ndst) dropped — the tables lgu_ba_assemble_f64 walks."""
+    import numpy as np
+    from lgu_slam_amd import ba as B
+    dest = np.array([2, -1, 0, 2, 5, 0, 7, 2])
+    ptr, idx = B._csr(dest, 6, torch.device("cpu"))
+    assert ptr.tolist() == [0, 2, 2, 5, 5, 5, 6]
+    assert idx.tolist() == [2, 5, 0, 3, 7, 4]
+    ptr, idx = B._csr(np.array([-1, 9]), 3, torch.device("cpu"))
+    assert ptr.tolist() == [0, 0, 0, 0] and idx.numel() == 1   # placeholder entry keeps the pointer valid
