@@ -8,6 +8,15 @@ of synthetic edges: BASELINE config 2 — 48x64 fmap, L=4, r=3, E=20 edges per G
 kernel launch.  With --probe the level-1 uncertainty probe of corr.py:94-99 is timed in
 the step as well.  Inputs are resident in HBM before the timed region.
 
+Cache mode (--cache, default cold): the lines one launch touches (~243 MiB) would fit the
+256 MiB Infinity Cache if every step replayed the same inputs, so the headline rotates over
+--sets (4) disjoint input sets: every launch is HBM-served, as a lookup inside the SLAM loop
+is.  `extra.warm_cache` holds the replay figure next to it.
+
+`extra` (N=1): the production call (probe fused in), the reference-layout operator path,
+BASELINE config 3 (E=40) and config 4 (lowmem) — each the median of --blocks blocks of
+--steps launches, device time by HIP events on the launch stream.
+
 Multi-GPU (--gpus N, launched by torch.distributed.run): factor-graph edges are
 independent, so every rank samples its own E edges (weak scaling, no data-path
 collective); `value` = all ranks' units / max-over-ranks time.  The sharded driver's one
@@ -198,13 +207,80 @@ def emit(obj):
         os.write(_REAL_STDOUT, line)
 
 
-def lowmem_main(args, ops, dev, rank, world, use_dist):
-    """BASELINE config 4: lowMem_defSample (no stored volume), 640x480 input -> 60x80 feature maps of 128 channels kept
-    in half precision as the SLAM system stores them, L=4, r=3, one chunk of `--edges` edges per GPU.  One step = the
-    per-level loop of AltCorrBlock.corr_fn (corr.py:192-213) = ONE fused launch (lgu_lowmem_pyramid_fwd_h16)."""
-    B, H1, W1, C, L, R = args.edges, 60, 80, 128, 4, 3
+def _events():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def time_blocks(step, steps, blocks, pre_block=None):
+    """Device time per step (ms) of `blocks` blocks of `steps` back-to-back launches, HIP events on torch's current
+    stream (the stream every launch goes to).  step(i) is given the global launch index.  Returns the list of per-block
+    averages; callers report the median."""
+    res, n = [], 0
+    for _ in range(blocks):
+        if pre_block is not None:
+            pre_block()
+        e0, e1 = _events()
+        e0.record()
+        for _ in range(steps):
+            step(n)
+            n += 1
+        e1.record()
+        e1.synchronize()
+        res.append(e0.elapsed_time(e1) / steps)
+    return res
+
+
+class DefcorrSets:
+    """`nsets` independent input sets (volumes, coords, offsets) of E edges each and one prepared launch per set.
+    Launch i uses set i % nsets: with nsets >= 3 two uses of the same line are separated by the other sets' launches
+    (nsets - 1) x ~255 MB of touched lines, more than the 256 MiB Infinity Cache holds (MI355X_MICROARCH.md, Infinity
+    Cache: a table stays resident only while table + everything touched in between fits) — every launch is HBM-served,
+    as a lookup in the SLAM loop is (GRU / convolution / BA kernels run between lookups, factor_graph.py:204-254).
+    nsets = 1 is the warm mode: every launch re-touches the same lines."""
+
+    def __init__(self, ops, E, nsets, seed, dev, randn_volumes=False, keep_rowmajor=False):
+        self.E, self.H1, self.W1, self.L, self.R = E, 48, 64, 4, 3
+        self.ops, self.dev, self.nsets = ops, dev, nsets
+        self.level_hw = [(self.H1 >> l, self.W1 >> l) for l in range(self.L)]
+        self.rowmajor, self.tiled, self.coords, self.offs, self.offs1_saved = [], [], [], [], []
+        for s in range(nsets):
+            vols, coords, offs = make_inputs(E, self.H1, self.W1, self.L, self.R, seed + 7919 * s, dev, from_fmaps=not randn_volumes)
+            self.tiled.append([ops.volume_retile(v) for v in vols])
+            # set 0's row-major form is what algorithmic_bytes_per_unit counts from; the others only if asked for
+            self.rowmajor.append(vols if (keep_rowmajor or s == 0) else None)
+            self.coords.append(coords)
+            self.offs.append(offs)
+            self.offs1_saved.append(offs[1].clone())
+        self.out = torch.empty(E, self.L * 49, self.H1, self.W1, device=dev)
+        self.units = E * self.H1 * self.W1
+
+    def plans(self, layout="tiled", probe=False, out_format="planar"):
+        tiled = layout == "tiled"
+        ps = []
+        for s in range(self.nsets):
+            ps.append(self.ops.DefcorrPyramidPlan(self.tiled[s] if tiled else self.rowmajor[s], self.offs[s], self.R, probe=probe,
+                                                  tiled=tiled, level_hw=self.level_hw if tiled else None, out_format=out_format))
+        return ps
+
+    def restore_offsets(self):
+        """The fused probe scales offset[1] in place on every call (corr.py:99, persistent); a CorrBlock lives for 8-16
+        lookups, so timed blocks of probe-on launches restart from the original offsets."""
+        for s in range(self.nsets):
+            self.offs[s][1].copy_(self.offs1_saved[s])
+
+    def stepper(self, plans, out, cold=True):
+        n = self.nsets if cold else 1
+
+        def step(i):
+            s = i % n
+            plans[s](self.coords[s], out=out)
+        return step
+
+
+def lowmem_setup(ops, dev, B, seed):
+    H1, W1, C, L, R = 60, 80, 128, 4, 3
     g = torch.Generator(device=dev)
-    g.manual_seed(4321 + rank)
+    g.manual_seed(seed)
 
     def randn(*s):
         return torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
@@ -218,7 +294,51 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
     o1 = ((4 * torch.tanh(randn(B, H1, W1, 7, 7, 2)) + o0) / 2).contiguous()
     plan = ops.LowmemPyramidPlan(f1, f2s, [o0, o1, None, None], R)
     out = torch.empty(B, 1, L * 49, H1, W1, device=dev)
-    units = B * H1 * W1
+    return dict(B=B, H1=H1, W1=W1, C=C, L=L, R=R, f1=f1, f2s=f2s, coords=coords, o0=o0, o1=o1, plan=plan, out=out,
+                units=B * H1 * W1)
+
+
+def lowmem_roofline(S, dev_ms):
+    """Roofline record of the low-memory launch: the contraction against the dense f16 MFMA peak, and the compulsory HBM
+    bytes (feature maps once + offsets + coords + out) against the HBM peak."""
+    flop_unit = 49 * S["L"] * 4 * S["C"] * 2  # SURVEY §8(d): taps x levels x corners x channels x 2
+    kern_s = dev_ms * 1e-3
+    achieved = flop_unit * S["units"] / kern_s / 1e12
+    hbm_unit = (1 + 1.328) * S["C"] * 2 + 784 + 784 + 8  # half maps: fmap1 + fmap2 pyramid, out, offsets of 2 levels, coords
+    return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
+            "traffic": None, "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem kernels (csrc/lowmem_*.hip)",
+            "device_ms_per_step": dev_ms,
+            "hbm_compulsory_bytes_per_unit": hbm_unit, "hbm_compulsory_GBps": hbm_unit * S["units"] / kern_s / 1e9,
+            "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "
+                    "launch is bound by moving the swept windows of fmap2 to the matrix cores (DESIGN.md §3.4), not by the "
+                    "MFMA rate"}
+
+
+def lowmem_cpu_baseline(S):
+    from oracle import oracle as O
+    Bs, H1, W1, C, L, R = 1, S["H1"], S["W1"], S["C"], S["L"], S["R"]
+    a1, a2 = S["f1"][:Bs].float().cpu().numpy(), [f[:Bs].float().cpu().numpy() for f in S["f2s"]]
+    cc = S["coords"][:Bs].cpu().numpy()
+    oo = [S["o0"][:Bs].cpu().numpy(), S["o1"][:Bs].cpu().numpy(), np.zeros((Bs, H1, W1, 7, 7, 2), np.float32),
+          np.zeros((Bs, H1, W1, 7, 7, 2), np.float32)]
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < 10.0 and len(times) < 50):
+        t1 = time.perf_counter()
+        for l in range(L):
+            O.lowMem_defSample(a1, a2[l], (cc / 2 ** l).astype(np.float32), oo[l].copy(), R)
+        times.append(time.perf_counter() - t1)
+    return {"value": Bs * H1 * W1 / float(np.median(times)) / 1e6, "unit": "Mpix·edges/s", "cores": 1, "kind": "port",
+            "sample": "C restatement of lowMem_defSample (oracle/lgu_oracle.c), 4 levels, %d edge of %dx%dx%d, median of %d reps "
+                      "(%.1f s of CPU work)" % (Bs, H1, W1, C, len(times), sum(times))}
+
+
+def lowmem_main(args, ops, dev, rank, world, use_dist):
+    """BASELINE config 4: lowMem_defSample (no stored volume), 640x480 input -> 60x80 feature maps of 128 channels kept
+    in half precision as the SLAM system stores them, L=4, r=3, one chunk of `--edges` edges per GPU.  One step = the
+    per-level loop of AltCorrBlock.corr_fn (corr.py:192-213) = ONE fused launch (lgu_lowmem_pyramid_fwd_h16)."""
+    S = lowmem_setup(ops, dev, args.edges, 4321 + rank)
+    plan, coords, out, units = S["plan"], S["coords"], S["out"], S["units"]
 
     def barrier():
         if use_dist:
@@ -229,7 +349,7 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
     for _ in range(args.warmup):
         plan(coords, out=out)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
@@ -244,44 +364,49 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     if rank == 0:
-        flop_unit = 49 * L * 4 * C * 2  # taps x levels x corners x channels x 2
-        kern_s = dev_ms * 1e-3 / args.steps
-        achieved = flop_unit * units / kern_s / 1e12
-        cpu = None
-        if not (args.no_cpu or world > 1):
-            from oracle import oracle as O
-            Bs = 1
-            a1, a2 = f1[:Bs].float().cpu().numpy(), [f[:Bs].float().cpu().numpy() for f in f2s]
-            cc = coords[:Bs].cpu().numpy()
-            oo = [o0[:Bs].cpu().numpy(), o1[:Bs].cpu().numpy(), np.zeros((Bs, H1, W1, 7, 7, 2), np.float32), np.zeros((Bs, H1, W1, 7, 7, 2), np.float32)]
-            times = []
-            t_start = time.perf_counter()
-            while len(times) < 2 or (time.perf_counter() - t_start < 10.0 and len(times) < 50):
-                t1 = time.perf_counter()
-                for l in range(L):
-                    O.lowMem_defSample(a1, a2[l], (cc / 2 ** l).astype(np.float32), oo[l].copy(), R)
-                times.append(time.perf_counter() - t1)
-            cpu = {"value": Bs * H1 * W1 / float(np.median(times)) / 1e6, "unit": "Mpix·edges/s", "cores": 1, "kind": "port",
-                   "sample": "C restatement of lowMem_defSample (oracle/lgu_oracle.c), 4 levels, %d edge of %dx%dx%d, median of %d reps "
-                             "(%.1f s of CPU work)" % (Bs, H1, W1, C, len(times), sum(times))}
+        blocks = time_blocks(lambda i: plan(coords, out=out), args.steps, args.blocks)
+        roof = lowmem_roofline(S, float(np.median(blocks)))
+        roof["device_ms_per_step_blocks"] = blocks
         res = {"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4)",
                "value": world * units / (wall / args.steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16 features, f32 accumulate", "data": "synthetic",
                "config": {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, one chunk of "
-                                      "%d edges per GPU, all levels in one launch" % B,
-                          "edges_per_gpu": B, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)"},
-               "roofline": {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-                            "traffic": None, "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_mfma_kernel<3,4>",
-                            "device_ms_per_step": dev_ms / args.steps,
-                            "note": "the contraction is 2.2 % of the dense f16 MFMA peak by design: the kernel is bound by L2 -> CU "
-                                    "reads of the swept windows (DESIGN.md §3.4), the matrix cores are idle most of the time"},
-               "cpu_baseline": cpu}
+                                      "%d edges per GPU, all levels in one launch" % S["B"],
+                          "edges_per_gpu": S["B"], "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)"},
+               "roofline": roof,
+               "cpu_baseline": None if (args.no_cpu or world > 1) else lowmem_cpu_baseline(S)}
         emit(res)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_name(variant, probe, tiled, out_format):
+    kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
+             5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
+             3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
+             2: "lgu::defcorr_generic_kernel%s"}.get(variant, "?%s") % (("true" if probe else "false") if variant != 2 else "")
+    kname = kname.replace("LAYOUT", "true" if tiled else "false")
+    if "gather_kernel" in kname:  # trailing template argument = output form; channel-last forms run 8-pixel tiles
+        om = {"planar": 0, "nhwc": 1, "nhwc_f16": 2}[out_format]
+        kname = (kname.replace(",2,16,", ",2,8,") if om else kname)[:-1] + ",%d>" % om
+    return kname
+
+
+def load_traffic(kname, cache, tiled):
+    """HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 x2 fetch correction; tools/gpu_full_run.sh): counters cannot be collected from inside the timed
+    process.  Newest round first; only a file measured in the same cache mode and layout on the same kernel is used."""
+    lay = "tiled" if tiled else "rowmajor"
+    for tname in ("traffic_r02_%s_%s.json" % (cache, lay),):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile):
+            t = json.load(open(tfile))
+            if t.get("kernel") == kname and t.get("cache") == cache:
+                return t["hbm_bytes_per_launch"], "profiles/" + tname
+    return None, None
 
 
 def main():
@@ -301,6 +426,14 @@ def main():
     ap.add_argument("--out-format", choices=["planar", "nhwc", "nhwc_f16"], default="planar",
                     help="output tensor: 'planar' = the reference's contiguous (E,196,H,W) fp32; 'nhwc' / 'nhwc_f16' = the "
                          "same values channel-last in fp32 / half, the form the consumer 1x1 convolution takes (tiled layout only)")
+    ap.add_argument("--cache", choices=["cold", "warm"], default="cold",
+                    help="'cold' (default, the headline): consecutive launches rotate over --sets disjoint input sets so that no "
+                         "line touched by a launch is still in the 256 MiB Infinity Cache when it is touched again; 'warm': "
+                         "every launch re-reads the same inputs (round 1's mode)")
+    ap.add_argument("--sets", type=int, default=4, help="input sets rotated in cold mode (>= 3)")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps launches per 'extra' figure (median reported)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 'extra' figures (probe on, row-major operator path, "
+                    "config 3, config 4, warm cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -317,6 +450,8 @@ def main():
         return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.cache == "cold" and args.sets < 3:
+        raise SystemExit("--cache cold needs --sets >= 3")
     quiet_stdout()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -334,26 +469,22 @@ def main():
         return lowmem_main(args, ops, dev, rank, world, use_dist)
 
     E, H1, W1, L, R = args.edges, 48, 64, 4, 3
-    vols, coords, offs = make_inputs(E, H1, W1, L, R, 1234 + rank, dev, from_fmaps=not args.randn_volumes)
-    out = torch.empty(E, L * 49, H1, W1, device=dev)
-    units = E * H1 * W1
-
-    # prepared launch: pointer tables built once, one ctypes call per step (the kernel is
-    # ~60 us; per-call Python argument handling would otherwise bound the loop)
+    cold = args.cache == "cold"
     tiled = args.layout == "tiled"
-    level_hw = [(H1 >> l, W1 >> l) for l in range(L)]
-    if tiled:  # what CorrBlock.__init__ (ops.volume_pyramid(tiled=True)) leaves in HBM; conversion is setup, not timed
-        rowmajor_vols = vols
-        vols = [ops.volume_retile(v) for v in rowmajor_vols]
-    plan = ops.DefcorrPyramidPlan(vols, offs, R, probe=args.probe, tiled=tiled, level_hw=level_hw,
-                                  out_format=args.out_format)
+    want_extra = rank == 0 and world == 1 and not args.no_extra
+    # what CorrBlock.__init__ (ops.volume_pyramid(tiled=True)) leaves in HBM; building it is setup, not timed
+    sets = DefcorrSets(ops, E, args.sets if cold else 1, 1234 + rank, dev, args.randn_volumes,
+                       keep_rowmajor=(not tiled) or want_extra)
+    units = sets.units
+    # prepared launches: pointer tables built once, one ctypes call per step (the kernel is ~50 us; per-call Python
+    # argument handling would otherwise bound the loop)
+    plans = sets.plans(args.layout, args.probe, args.out_format)
+    out = sets.out
     if args.out_format != "planar":
         out = ops._pyr_out(args.out_format, E, L * (2 * R + 1) ** 2, H1, W1, dev, None)
-
-    def step():
-        # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful
-        # offset[1] *= mask of corr.py:94-99 run inside the same launch
-        plan(coords, out=out)
+    # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful offset[1] *= mask of corr.py:94-99 run
+    # inside the same launch
+    step = sets.stepper(plans, out, cold)
 
     def barrier():
         if use_dist:
@@ -361,14 +492,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    if args.probe:
+        sets.restore_offsets()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = _events()
     t0 = time.perf_counter()
     ev0.record()  # kernels are enqueued on torch's current stream, which these events time
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -401,29 +534,23 @@ def main():
                     "ms": float(t.item()) * 1e3}
 
     if rank == 0:
-        A, U = algorithmic_bytes_per_unit(rowmajor_vols if tiled else vols, coords, offs, R)
+        A, U = algorithmic_bytes_per_unit(sets.rowmajor[0], sets.coords[0], sets.offs[0], R)
+        A_planar = A
         if args.out_format == "nhwc_f16":  # the output row is 2-byte elements
             A -= L * (2 * R + 1) ** 2 * 2
-        kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
-                 5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
-                 3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
-                 2: "lgu::defcorr_generic_kernel%s"}.get(args.variant, "?%s") % (("true" if args.probe else "false") if args.variant != 2 else "")
-        kname = kname.replace("LAYOUT", "true" if tiled else "false")
-        if "gather_kernel" in kname:  # trailing template argument = output form; channel-last forms run 8-pixel tiles
-            om = {"planar": 0, "nhwc": 1, "nhwc_f16": 2}[args.out_format]
-            kname = (kname.replace(",2,16,", ",2,8,") if om else kname)[:-1] + ",%d>" % om
-        # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 x2 fetch correction): measured offline
-        # because counters cannot be collected from inside the timed process; see profiles/.
-        traffic, traffic_src = None, None
-        tname = "traffic_r01_tiled.json" if tiled else "traffic_r01.json"
-        tfile = os.path.join(ROOT, "profiles", tname)
-        if os.path.exists(tfile) and E == 20 and not args.probe and args.out_format == "planar":
-            t = json.load(open(tfile))
-            if t.get("kernel") == kname:
-                traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/" + tname
-        kern_s = dev_ms * 1e-3 / args.steps  # average launch-to-launch device time of the step
-        achieved = A * units / kern_s / 1e9
+        kname = kernel_name(args.variant, args.probe, tiled, args.out_format)
+        traffic, traffic_src = (None, None)
+        if E == 20 and not args.probe and args.out_format == "planar":
+            traffic, traffic_src = load_traffic(kname, args.cache, tiled)
+        # headline device time: median over blocks of --steps launches in the headline's own mode (HIP events on the
+        # launch stream); the single timed region above gives `value` / `ms_per_step` per the driver contract
+        pre = sets.restore_offsets if args.probe else None
+        hb = time_blocks(step, min(args.steps, 16) if args.probe else args.steps, args.blocks, pre)
+        kern_ms = float(np.median(hb))
+        achieved = A * units / (kern_ms * 1e-3) / 1e9
+        cache_note = ("cold: launches rotate over %d disjoint input sets (%d x ~255 MB of touched lines between two uses of a "
+                      "line > 256 MiB Infinity Cache), every launch HBM-served" % (args.sets, args.sets - 1)) if cold else \
+                     "warm: every launch re-reads the same inputs (touched set ~243 MiB can stay in the Infinity Cache)"
         res = {
             "metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)",
             "value": value, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -431,6 +558,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: TartanAir-mono shape, 48x64 fmap, L=4, r=3, "
                                    "%d edges per GPU, fused 4-level deformable sample%s" % (E, " + level-1 probe" if args.probe else ""),
+                       "probe": "on (fused in the launch)" if args.probe else
+                                "off (BASELINE.json's metric: the 4-level deformable sample alone; the production call with the "
+                                "level-1 probe fused in is extra.probe_on)",
+                       "cache": cache_note,
                        "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
                        "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid",
                        "pyramid_layout": "4x8-tiled slices (CorrBlock's own storage; results bit-identical)" if tiled
@@ -440,9 +571,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC)",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": A * units,
                          "algorithmic_bytes_per_unit": A, "unique_volume_elements_per_unit": U,
-                         "kernel": kname, "device_ms_per_step": dev_ms / args.steps},
-            "cpu_baseline": None if (args.no_cpu or world > 1) else cpu_baseline(E, H1, W1, L, R),  # rank 0, N=1 only
+                         "kernel": kname, "cache": args.cache,
+                         "device_ms_per_step": kern_ms, "device_ms_per_step_blocks": hb,
+                         "device_ms_per_step_timed_region": dev_ms / args.steps},
+            "cpu_baseline": None,
         }
+        if want_extra:
+            res["extra"] = extras(args, ops, dev, sets, A_planar, kern_ms)
+        if not (args.no_cpu or world > 1):  # rank 0, N=1 only
+            res["cpu_baseline"] = cpu_baseline(E, H1, W1, L, R)
         if exchange:
             res["exchange"] = exchange
         emit(res)
@@ -450,6 +587,64 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(args, ops, dev, sets, A, headline_ms):
+    """The figures VERDICT r01 asked to see in the driver-run line next to the headline (each the median of --blocks
+    blocks of --steps launches, device ms by HIP events, cold cache unless named warm): the production call with the
+    level-1 probe fused in, the reference-layout operator path, BASELINE config 3 (E = 40), BASELINE config 4 (lowmem),
+    and the headline kernel with a warm cache."""
+    E, units = sets.E, sets.units
+    steps, blocks = args.steps, args.blocks
+
+    def rec(ms_list, u=units, a=A, **kw):
+        ms = float(np.median(ms_list))
+        d = {"device_ms_per_step": ms, "Mpix_edges_per_s": u / ms / 1e3, "roofline_frac": a * u / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "blocks_ms": [round(x, 5) for x in ms_list]}
+        d.update(kw)
+        return d
+
+    ex = {"note": "device ms per launch, median of %d blocks of %d launches; cold cache (rotating %d input sets) unless named "
+                  "warm; roofline_frac = algorithmic bytes / time / 8 TB/s as for the headline" % (blocks, steps, sets.nsets)}
+    cold = sets.nsets > 1
+    # (a) production call: probe on (CorrBlock.__call__ always launches with the probe, corr.py:94-99)
+    pp = sets.plans("tiled", True, "planar")
+    sets.restore_offsets()
+    pblocks = min(max(blocks, -(-steps // 16)), 25)
+    ex["probe_on"] = rec(time_blocks(sets.stepper(pp, sets.out, cold), min(steps, 16), pblocks, sets.restore_offsets),
+                         workload="config 2 + fused level-1 probe (production CorrBlock.__call__), blocks of <= 16 launches "
+                                  "restarting from the original offsets (a CorrBlock serves 8-16 lookups)")
+    sets.restore_offsets()
+    # (b) reference-layout operator path (what defCorrSample.* drop-in callers get)
+    if all(v is not None for v in sets.rowmajor):
+        pr = sets.plans("rowmajor", False, "planar")
+        ex["rowmajor_operator_path"] = rec(time_blocks(sets.stepper(pr, sets.out, cold), steps, blocks),
+                                           workload="config 2 over row-major slices (reference operator layout)")
+    # (e) warm cache, headline kernel
+    pt = sets.plans("tiled", False, "planar")
+    ex["warm_cache"] = rec(time_blocks(sets.stepper(pt, sets.out, False), steps, blocks),
+                           workload="config 2, every launch on the same inputs (round 1's mode)")
+    ex["cold_over_warm"] = headline_ms / ex["warm_cache"]["device_ms_per_step"] if args.cache == "cold" and not args.probe else None
+    # (c) BASELINE config 3: EuRoC stereo, ~2x edge count
+    del pp, pt
+    s40 = DefcorrSets(ops, 2 * E, 3 if cold else 1, 4242, dev, args.randn_volumes)
+    p40 = s40.plans("tiled", False, "planar")
+    ex["config3_E40"] = rec(time_blocks(s40.stepper(p40, s40.out, cold), steps, blocks), u=s40.units,
+                            workload="BASELINE config 3: %d edges per launch (stereo + temporal), tiled" % (2 * E))
+    ex["config3_E40"]["device_us_per_edge"] = ex["config3_E40"]["device_ms_per_step"] * 1e3 / (2 * E)
+    p40p = s40.plans("tiled", True, "planar")
+    ex["config3_E40_probe_on"] = rec(time_blocks(s40.stepper(p40p, s40.out, cold), min(steps, 16), pblocks, s40.restore_offsets), u=s40.units,
+                                     workload="config 3 with the fused probe")
+    del s40, p40, p40p
+    torch.cuda.empty_cache()
+    # (d) BASELINE config 4: lowmem
+    S = lowmem_setup(ops, dev, 16, 4321)
+    lb = time_blocks(lambda i: S["plan"](S["coords"], out=S["out"]), steps, blocks)
+    lm = float(np.median(lb))
+    ex["config4_lowmem"] = {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, 16 edges, all "
+                                        "levels in one launch", "device_ms_per_step": lm, "Mpix_edges_per_s": S["units"] / lm / 1e3,
+                            "blocks_ms": [round(x, 5) for x in lb], "roofline": lowmem_roofline(S, lm)}
+    return ex
 
 
 if __name__ == "__main__":
