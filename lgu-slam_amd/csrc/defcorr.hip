@@ -33,6 +33,10 @@
 
 namespace lgu {
 
+// csrc/defcorr_lean.hip: the production configuration (radius 3, 4 levels, offsets on levels 0-1, planar output)
+int lean_pyramid_forward(const float* const* volumes, const float* coords, float* const* offsets, float* out, int E,
+                         int H1, int W1, const int* H2, const int* W2, int flags, const int* edge_slot, hipStream_t st);
+
 constexpr int TP = 16;               // pixels (along x) per workgroup of the staged kernel / narrow gather tiles
 constexpr int NWAVE = 4;             // waves per workgroup
 constexpr int PPW = TP / NWAVE;      // pixels per wave
@@ -64,6 +68,9 @@ struct PyrParams {
   const void* enc_w;  // half (ENC_N, enc_kp): W1 rows zero-padded from Ctot to enc_kp = ceil(Ctot / 32) * 32 entries
   const void* enc_b;  // half (ENC_N)
   int enc_kp;
+  // L2 prefetch distance in tiles (0 = off): a workgroup touches the offset lines of the tile `pf_tiles` further on,
+  // which a later workgroup of the same XCD samples (set by the launcher for 16-pixel tiles in XCD-aware order)
+  int pf_tiles;
 };
 
 constexpr int PYR_INT_XCD_REMAP = 1 << 16;  // internal flag, set by the launcher
@@ -444,7 +451,15 @@ __global__ __launch_bounds__(NWAVE * kWave) void defcorr_pyr_kernel(const PyrPar
 // v_mfma_f32_16x16x32_f16, A = 16 output channels of W1 (16 contiguous bytes per lane from the zero-padded weight
 // rows), B = 16 pixels of the LDS tile, one 16 x 16 output tile per wave (8 channel tiles x 2 pixel tiles = the 16
 // waves), fp32 accumulation, + bias, ReLU, half — and only the (E, H1, W1, 128) half result goes to HBM.
-template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED, int OUTM = 0>
+// PAIR: an offset level's corners are fetched as two 8-byte x-pairs (top row, bottom row) instead of four 4-byte
+// gathers.  The vector L1 serves a gather quad by quad (4 lanes), one access per distinct line in the quad, and at
+// ~39 accesses per corner instruction that access rate — not HBM — bounds the 4-byte form (profiles/r02_pmc_cold.txt:
+// 771 L1 accesses per wave, 0.86 per CU cycle).  A pair never leaves its line except when the tap's x is the last
+// column of a 4 x 8 tile (1 lane in 8): those lanes fetch the pair one element to the left and take the right
+// neighbours with two extra instructions that only they execute.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int R, bool PROBE, int ZMASK, int GP, int TPX, bool TILED, int OUTM = 0, bool PAIR = false>
 __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) void defcorr_gather_kernel(const PyrParams p) {
   constexpr int RD = 2 * R + 1, NT = RD * RD;
   constexpr int LAT = 2 * R + 2;
@@ -463,6 +478,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     const int n8 = (int)(gridDim.x & ~7u);
     if (bid < n8) bid = (bid & 7) * (n8 >> 3) + (bid >> 3);
   }
+  const int tile_lin = bid;
   const int tile = bid % p.tiles_per_row;
   bid /= p.tiles_per_row;
   const int y = bid % p.H1;
@@ -548,9 +564,9 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
   // for them), then everything that does not depend on the probe, then level 1.
   float platv[GP];
   float latv[GP][FASTL];
-  float q[GP][FASTL][4];
+  float q[GP][FASTL][PAIR && TILED ? 6 : 4];
   float gdx[GP][FASTL], gdy[GP][FASTL];
-  int gflag[GP][FASTL];  // bit0 tap valid, bit1 x2 in bounds, bit2 y2 in bounds
+  int gflag[GP][FASTL];  // bit0 tap valid, bit1 x2 in bounds, bit2 y2 in bounds, bit3 (PAIR) pair fetched one element to the left
 #pragma unroll
   for (int k = 0; k < GP; k++) {
     platv[k] = 0.0f;
@@ -579,6 +595,28 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     const bool xin = x1 + 1 < W2, yin = y1 + 1 < H2;
     gflag[k][l] = (valid ? 1 : 0) | (xin ? 2 : 0) | (yin ? 4 : 0);
     const int dxo = xin ? step_x<TILED>(xc) : 0, dyo = yin ? step_y<TILED>(yc, W2, p.tpr[l]) : 0;
+    if constexpr (PAIR) {
+      // last column of a tile (tiled) / of the slice (row-major): the pair starts one element to the left
+      const bool shift = TILED ? ((xc & 7) == 7) : (xc == W2 - 1);
+      const int xa = xc - (shift ? 1 : 0);
+      const int yb = yc + 1 < H2 ? yc + 1 : yc;
+      gflag[k][l] |= shift ? 8 : 0;
+      const float* base = p.vol[l] + (vrow_pix + (pv ? px : 0)) * (size_t)p.ssz[l];
+      const int pa = slice_pos<TILED>(yc, xa, W2, p.tpr[l]);
+      const int pb = TILED ? pa + (yb != yc ? step_y<TILED>(yc, W2, p.tpr[l]) : 0) : pa + (yb != yc ? W2 : 0);
+      const f32x2u a = *reinterpret_cast<const f32x2u*>(base + pa);
+      const f32x2u b = *reinterpret_cast<const f32x2u*>(base + pb);
+      q[k][l][0] = a.x; q[k][l][1] = a.y; q[k][l][2] = b.x; q[k][l][3] = b.y;
+      if constexpr (TILED) {
+        // right neighbours across the tile boundary: element (y, x + 1) = first column of the next tile, 26 floats on
+        q[k][l][4] = q[k][l][5] = 0.0f;
+        if (shift && xin) {
+          q[k][l][4] = base[pa + 26];
+          q[k][l][5] = base[pb + 26];
+        }
+      }
+      return;
+    }
     const float* s = p.vol[l] + (vrow_pix + (pv ? px : 0)) * (size_t)p.ssz[l] + slice_pos<TILED>(yc, xc, W2, p.tpr[l]);
     q[k][l][0] = s[0];
     q[k][l][1] = s[dxo];
@@ -596,6 +634,7 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       gdx[k][l] = gdy[k][l] = 0.0f;
       gflag[k][l] = 0;
       q[k][l][0] = q[k][l][1] = q[k][l][2] = q[k][l][3] = 0.0f;
+      if constexpr (PAIR && TILED) q[k][l][4] = q[k][l][5] = 0.0f;
       if (l >= p.L) continue;
       const int H2 = p.H2[l], W2 = p.W2[l];
       if ((ZMASK >> l) & 1) {
@@ -647,6 +686,19 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     }
   }
 
+  if constexpr (OUTM == 0 && TPX == 16) {
+    // ---- L2 prefetch for a later workgroup of this XCD.  A lookup is a chain of two dependent HBM round trips
+    // (offsets, then the gathers they address); the offsets of tile t + pf_tiles are sampled by the workgroup this XCD
+    // starts pf_tiles dispatches from now, so touching their lines now (one dword per 128-byte line, straight into an
+    // LDS scratch word by LDS-DMA: no register, nothing ever waits for it) turns that workgroup's first round trip
+    // into L2 hits.  16 pixels x 49 taps x 8 B = 49 lines per level; wave l touches level l.  Issued behind this
+    // wave's own gathers (loads return in order).
+    if (p.pf_tiles > 0 && w < FASTL && !((ZMASK >> w) & 1) && w < p.L && tile_lin + p.pf_tiles < (int)gridDim.x && lane < NT) {
+      const char* src = reinterpret_cast<const char*>(p.off[w]) + ((size_t)(tile_lin + p.pf_tiles) * TPX * NT * 8 + lane * 128);
+      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(outst + p.L * NT * (TPX + 1) + w * kWave), 4, 0, 0);
+    }
+  }
+
   // ---- phase B: blend, park in the transpose tile (or store the channel-last row directly) ----
   auto put = [&](int l, int ch, int pc, float val) __attribute__((always_inline)) {
     if constexpr (OUTM == 0) {
@@ -690,10 +742,25 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
       }
       if (!pv) continue;
       const int fl = gflag[k][l];
-      const float q21 = (fl & 2) ? q[k][l][1] : 0.0f;          // :76-80 out-of-range corners read as 0
-      const float q12 = (fl & 4) ? q[k][l][2] : 0.0f;
-      const float q22 = ((fl & 6) == 6) ? q[k][l][3] : 0.0f;
-      const float val = (fl & 1) ? bilerp(q[k][l][0], q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
+      float q11, q21, q12, q22;
+      if constexpr (PAIR) {
+        const bool sh = (fl & 8) != 0;
+        q11 = sh ? q[k][l][1] : q[k][l][0];
+        q12 = sh ? q[k][l][3] : q[k][l][2];
+        if constexpr (TILED) {
+          q21 = sh ? q[k][l][4] : q[k][l][1];
+          q22 = sh ? q[k][l][5] : q[k][l][3];
+        } else {  // row-major: a shifted pair means x + 1 is outside the slice, masked below
+          q21 = q[k][l][1];
+          q22 = q[k][l][3];
+        }
+      } else {
+        q11 = q[k][l][0]; q21 = q[k][l][1]; q12 = q[k][l][2]; q22 = q[k][l][3];
+      }
+      q21 = (fl & 2) ? q21 : 0.0f;          // :76-80 out-of-range corners read as 0
+      q12 = (fl & 4) ? q12 : 0.0f;
+      q22 = ((fl & 6) == 6) ? q22 : 0.0f;
+      const float val = (fl & 1) ? bilerp(q11, q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
       if (tap) put(l, lane, w * GP + k, val);
     }
   }
@@ -802,13 +869,14 @@ static size_t pyr_lds_bytes(int L, int radius) {
 // KIND 0: LDS-DMA staged kernel; 1-3: register-gather kernel (4 px/wave; 2 px/wave with 16- / 32-pixel tiles);
 // 4 / 5: the 2 px/wave gather kernel over the TILED volume layout (16- / 32-pixel tiles);
 // 8: KIND 5 with the fused corr_encoder layer; 9 / 10: the tiled gather kernel with channel-last half / fp32 output
-// (no LDS, no barrier: 8-pixel tiles = 4-wave workgroups, which refill freed wave slots sooner than 16-wave ones)
+// (no LDS, no barrier: 8-pixel tiles = 4-wave workgroups, which refill freed wave slots sooner than 16-wave ones);
+// 11 / 12: KIND 4 / 2 fetching the corners as 8-byte x-pairs (production for the tiled / row-major planar output)
 template <int R, bool PROBE, int ZMASK, int KIND>
 static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
-  constexpr int tpx = KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
+  constexpr int tpx = KIND >= 11 ? 16 : KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
-                     : KIND >= 9 ? 0 : sizeof(float) * (size_t)p.L * nt_ * (tpx + 1);
+                     : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1) + FASTL * kWave) + (size_t)env_int("LGU_LDS_PAD", 0);
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
@@ -819,8 +887,10 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   else if constexpr (KIND == 5) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
   else if constexpr (KIND == 8) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
   else if constexpr (KIND == 9) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 2>;
-  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 1>;
-  const int nthreads = KIND >= 9 ? (tpx / 2) * kWave : (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
+  else if constexpr (KIND == 10) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 1>;
+  else if constexpr (KIND == 11) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true, 0, true>;
+  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false, 0, true>;
+  const int nthreads = KIND >= 11 ? 8 * kWave : KIND >= 9 ? (tpx / 2) * kWave : (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
   static bool attr_set = false;  // idempotent; racing setters write the same value
@@ -829,7 +899,12 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
     attr_set = true;
   }
   const unsigned grid = (unsigned)((size_t)q.E * q.H1 * q.tiles_per_row);
-  if (KIND == 2 || KIND == 4) q.flags |= PYR_INT_XCD_REMAP;  // 16-pixel tiles with planar output
+  q.pf_tiles = 0;
+  if (KIND == 2 || KIND == 4 || KIND >= 11) {  // 16-pixel tiles with planar output
+    q.flags |= PYR_INT_XCD_REMAP;
+    // prefetch distance: ~ a third of the workgroups an XCD holds at once (32 CUs x 4), i.e. a few microseconds ahead
+    if (q.W1 % tpx == 0 && grid % 8 == 0) q.pf_tiles = env_int("LGU_DEFCORR_PF", 0);
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, q);
   return launch_status();
 }
@@ -858,8 +933,10 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nt = (2 * radius + 1) * (2 * radius + 1);
   const int Ctot = L * nt;
-  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production (register-gather kernel, 2 px/wave, 16-pixel tiles in
-  // XCD-aware order; 8-pixel tiles for the channel-last output forms), 4 = 32-pixel tiles, 5 = 16-pixel tiles (= 0),
+  // LGU_DEFCORR_VARIANT (debug/A-B only): 0 = production (csrc/defcorr_lean.hip for CorrBlock's configuration, else the
+  // register-gather kernel with 8-byte pair fetches, 2 px/wave, 16-pixel tiles in XCD-aware order; 8-pixel tiles for the
+  // channel-last output forms), 7 = the general pair-fetch kernel everywhere, 6 = 4-byte corner gathers (round 1's
+  // production), 4 = 32-pixel tiles, 5 = 6,
   // 3 = 4 px/wave with 16-pixel tiles, 1 = LDS-DMA staged kernel, 2 = generic one-thread-per-output kernel
   // (independent cross-check)
   const int variant = env_int("LGU_DEFCORR_VARIANT", 0);
@@ -891,7 +968,7 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     for (int l = l0; l < l0 + nl; l++)
       fast = fast && (tiled || W2[l] % 4 == 0) && aligned16(volumes[l]) && (offsets[l] == nullptr || aligned16(offsets[l]));
     // the tiled layout is served by the production gather kernel at radius 3 only (what CorrBlock builds)
-    if (tiled && !(fast && radius == 3 && (variant == 0 || variant == 4 || variant == 5))) return LGU_E_UNSUPPORTED;
+    if (tiled && !(fast && radius == 3 && (variant == 0 || (variant >= 4 && variant <= 7)))) return LGU_E_UNSUPPORTED;
     // interleaved coords and slot-indirected volumes are served by the register-gather kernels only
     if ((coords_last || edge_slot) && !(fast && variant != 1)) return LGU_E_UNSUPPORTED;
     // channel-last / half output: production tiled kernel only
@@ -900,6 +977,11 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
     if (enc && !(tiled && variant == 0 && nl == L && enc_n == ENC_N && aligned16(enc_w) && aligned16(out) &&
                  (reinterpret_cast<uintptr_t>(enc_b) & 7) == 0))
       return LGU_E_UNSUPPORTED;
+    if (fast && variant == 0 && radius == 3 && L == FASTL && nl == FASTL && tmpl == 0xC && !enc && !out_nhwc) {
+      const int rc = lean_pyramid_forward(volumes, coords, offsets, out, E, H1, W1, H2, W2, flags, edge_slot, st);
+      if (rc == LGU_OK) { l0 += nl; continue; }
+      if (rc != LGU_E_UNSUPPORTED) return rc;
+    }
     if (fast) {
       PyrParams p;
       for (int l = 0; l < FASTL; l++) {
@@ -924,12 +1006,14 @@ static int pyramid_forward(const float* const* volumes, const float* coords, flo
       // two half-line writes of neighbouring tiles merge in one L2; variant 4 = 32-pixel tiles (full-line writes
       // from one workgroup, 16-wave workgroups), 3.5 % slower
       const bool wide = variant == 4;
+      const bool pair = variant == 0 || variant == 7;  // 8-byte x-pair fetches; variants 5 / 6 = the 4-byte corner gathers (A/B)
 #define LGU_LAUNCH(PR, ZM)                                                                                     \
   (enc ? launch_fast<3, PR, ZM, 8>(p, st) :                                                                    \
    out_f16 ? launch_fast<3, PR, ZM, 9>(p, st) : out_nhwc ? launch_fast<3, PR, ZM, 10>(p, st) :                  \
-   tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : launch_fast<3, PR, ZM, 4>(p, st))                        \
+   tiled ? (wide ? launch_fast<3, PR, ZM, 5>(p, st) : pair ? launch_fast<3, PR, ZM, 11>(p, st) : launch_fast<3, PR, ZM, 4>(p, st)) \
          : variant == 1 ? LGU_LAUNCH_K(PR, ZM, 0)                                                              \
-                        : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3) : LGU_LAUNCH_K(PR, ZM, 2))
+                        : variant == 3 ? LGU_LAUNCH_K(PR, ZM, 1) : wide ? LGU_LAUNCH_K(PR, ZM, 3)              \
+                        : pair ? LGU_LAUNCH_K(PR, ZM, 12) : LGU_LAUNCH_K(PR, ZM, 2))
       if (pr) rc = tmpl == 0xC ? LGU_LAUNCH(true, 0xC) : LGU_LAUNCH(true, 0x0);
       else rc = tmpl == 0xC ? LGU_LAUNCH(false, 0xC) : tmpl == 0xF ? LGU_LAUNCH(false, 0xF) : LGU_LAUNCH(false, 0x0);
 #undef LGU_LAUNCH
