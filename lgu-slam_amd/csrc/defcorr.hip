@@ -68,9 +68,6 @@ struct PyrParams {
   const void* enc_w;  // half (ENC_N, enc_kp): W1 rows zero-padded from Ctot to enc_kp = ceil(Ctot / 32) * 32 entries
   const void* enc_b;  // half (ENC_N)
   int enc_kp;
-  // L2 prefetch distance in tiles (0 = off): a workgroup touches the offset lines of the tile `pf_tiles` further on,
-  // which a later workgroup of the same XCD samples (set by the launcher for 16-pixel tiles in XCD-aware order)
-  int pf_tiles;
 };
 
 constexpr int PYR_INT_XCD_REMAP = 1 << 16;  // internal flag, set by the launcher
@@ -478,7 +475,6 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     const int n8 = (int)(gridDim.x & ~7u);
     if (bid < n8) bid = (bid & 7) * (n8 >> 3) + (bid >> 3);
   }
-  const int tile_lin = bid;
   const int tile = bid % p.tiles_per_row;
   bid /= p.tiles_per_row;
   const int y = bid % p.H1;
@@ -686,19 +682,6 @@ __global__ __launch_bounds__((TPX / GP) * kWave, GP == 4 ? (PROBE ? 4 : 5) : 8) 
     }
   }
 
-  if constexpr (OUTM == 0 && TPX == 16) {
-    // ---- L2 prefetch for a later workgroup of this XCD.  A lookup is a chain of two dependent HBM round trips
-    // (offsets, then the gathers they address); the offsets of tile t + pf_tiles are sampled by the workgroup this XCD
-    // starts pf_tiles dispatches from now, so touching their lines now (one dword per 128-byte line, straight into an
-    // LDS scratch word by LDS-DMA: no register, nothing ever waits for it) turns that workgroup's first round trip
-    // into L2 hits.  16 pixels x 49 taps x 8 B = 49 lines per level; wave l touches level l.  Issued behind this
-    // wave's own gathers (loads return in order).
-    if (p.pf_tiles > 0 && w < FASTL && !((ZMASK >> w) & 1) && w < p.L && tile_lin + p.pf_tiles < (int)gridDim.x && lane < NT) {
-      const char* src = reinterpret_cast<const char*>(p.off[w]) + ((size_t)(tile_lin + p.pf_tiles) * TPX * NT * 8 + lane * 128);
-      __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(outst + p.L * NT * (TPX + 1) + w * kWave), 4, 0, 0);
-    }
-  }
-
   // ---- phase B: blend, park in the transpose tile (or store the channel-last row directly) ----
   auto put = [&](int l, int ch, int pc, float val) __attribute__((always_inline)) {
     if constexpr (OUTM == 0) {
@@ -876,7 +859,7 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
   constexpr int tpx = KIND >= 11 ? 16 : KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
-                     : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1) + FASTL * kWave) + (size_t)env_int("LGU_LDS_PAD", 0);
+                     : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1)) + (size_t)env_int("LGU_LDS_PAD", 0);  // pad: occupancy experiments (tools/ab_cold.py)
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
@@ -899,12 +882,7 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
     attr_set = true;
   }
   const unsigned grid = (unsigned)((size_t)q.E * q.H1 * q.tiles_per_row);
-  q.pf_tiles = 0;
-  if (KIND == 2 || KIND == 4 || KIND >= 11) {  // 16-pixel tiles with planar output
-    q.flags |= PYR_INT_XCD_REMAP;
-    // prefetch distance: ~ a third of the workgroups an XCD holds at once (32 CUs x 4), i.e. a few microseconds ahead
-    if (q.W1 % tpx == 0 && grid % 8 == 0) q.pf_tiles = env_int("LGU_DEFCORR_PF", 0);
-  }
+  if (KIND == 2 || KIND == 4 || KIND >= 11) q.flags |= PYR_INT_XCD_REMAP;  // 16-pixel tiles with planar output
   hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, q);
   return launch_status();
 }

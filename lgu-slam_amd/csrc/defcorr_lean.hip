@@ -63,8 +63,12 @@ __device__ __forceinline__ T ldg(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
 }
 
-template <bool PROBE, bool TILED, int MINW>
-__global__ __launch_bounds__(NWV* kWave, MINW) void defcorr_lean_kernel(
+// Launch bound: 6 waves per SIMD = 3 workgroups per CU at <= 80 VGPRs.  The live set is 76 (the in-flight corners of
+// 2 pixels x 2 levels, their fractions, the lattice values, the offsets); capped at 64 the allocator spills loaded
+// values back to back with the loads (75.7 us).  Measured with LDS padding: a fourth resident workgroup buys the
+// general kernel 3 % (profiles/r02_ab_occupancy.jsonl), the third buys this one 4 %.
+template <bool PROBE, bool TILED>
+__global__ __launch_bounds__(NWV* kWave, 6) void defcorr_lean_kernel(
     const float* __restrict__ v0, const float* __restrict__ v1, const float* __restrict__ v2, const float* __restrict__ v3,
     float* __restrict__ off0, float* __restrict__ off1, const float* __restrict__ coords, float* __restrict__ out,
     const int* __restrict__ edge_slot, const Geo g, const int H1, const int W1, const int tiles_per_row,
@@ -362,16 +366,13 @@ int lean_pyramid_forward(const float* const* volumes, const float* coords, float
   const size_t lds = sizeof(float) * CH * PITCH + (size_t)env_int("LGU_LDS_PAD", 0);  // pad: occupancy experiments only
   const int remap = 1;
   const unsigned mt = magic_u32(tiles_per_row), mh = magic_u32((unsigned)H1);
-  const int minw = env_int("LGU_LEAN_W", 6);
-#define LGU_LEAN_(PR, TL, MW)                                                                                          \
-  hipLaunchKernelGGL((defcorr_lean_kernel<PR, TL, MW>), dim3((unsigned)grid), dim3(NWV* kWave), lds, st, volumes[0],    \
+#define LGU_LEAN(PR, TL)                                                                                               \
+  hipLaunchKernelGGL((defcorr_lean_kernel<PR, TL>), dim3((unsigned)grid), dim3(NWV* kWave), lds, st, volumes[0],        \
                      volumes[1], volumes[2], volumes[3], offsets[0], offsets[1], coords, out, edge_slot, g, H1, W1,    \
                      (int)tiles_per_row, mt, mh, (flags & LGU_PYR_COORDS_LAST) ? 1 : 0, remap)
-#define LGU_LEAN(PR, TL) do { if (minw >= 8) LGU_LEAN_(PR, TL, 8); else LGU_LEAN_(PR, TL, 6); } while (0)
   if (probe) { if (tiled) LGU_LEAN(true, true); else LGU_LEAN(true, false); }
   else { if (tiled) LGU_LEAN(false, true); else LGU_LEAN(false, false); }
 #undef LGU_LEAN
-#undef LGU_LEAN_
   return launch_status();
 }
 

@@ -18,7 +18,12 @@ ops = lgu_slam_amd.ops
 dev = torch.device("cuda:0")
 # variant[:prefetch distance], e.g. "0:0,0:48,6"
 # fourth field: LGU_LDS_PAD (extra LDS bytes per workgroup: limits workgroups per CU); third field: LGU_LEAN_W (launch bound of the lean kernel: 8 or 6 waves per SIMD)
-variants = [tuple(int(x) for x in (v + ":-1:-1:0").split(":")[:4]) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,6").split(",")]
+def _spec(v):
+    f = [int(x) for x in v.split(":")]
+    return tuple(f + [-1, -1, 0][len(f) - 1:])
+
+
+variants = [_spec(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,6").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 layouts = (sys.argv[3] if len(sys.argv) > 3 else "tiled,rowmajor").split(",")
 probes = [bool(int(v)) for v in (sys.argv[4] if len(sys.argv) > 4 else "0,1").split(",")]
