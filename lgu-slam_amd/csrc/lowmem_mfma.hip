@@ -35,8 +35,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int MM_BP = 16;            // pixels per wave = 4 x 4 block (MFMA rows)
 constexpr int MM_BOX = 16;           // patch row pitch / largest box side
 constexpr int MM_PP = MM_BOX * MM_BOX + 4;  // patch pitch per pixel: the 4 pixel groups of one scatter land on different bank quarters
-constexpr int MM_OUTP = 20;          // output transpose pitch (16 pixels + pad, 16-byte aligned rows)
-constexpr int MM_LDS_FLOATS = MM_BP * MM_PP + MM_BP * 4;
+constexpr int MM_MAXMT = 2;          // 4 x 4 pixel sub-blocks (MFMA row tiles) one wave can own
+__host__ __device__ constexpr int mm_outp(int MT) { return 16 * MT + 4; }  // output transpose pitch (pixels + pad, 16-byte aligned rows)
+__host__ __device__ constexpr int mm_lds_floats(int MT) { return MT * (MM_BP * MM_PP + MM_BP * 4); }
 
 // Element-type traits.  One k-step covers CPS channels; lane (lg, lx) holds EPL consecutive channels starting at
 // EPL * lg of row/column lx.  half: one v_mfma_f32_16x16x32_f16 per step.  float: four v_mfma_f32_16x16x4_f32 per
@@ -132,11 +133,17 @@ struct MmParams {
   const long long* jj;   // straight from the frame buffers — no gathered per-edge copies; null = fmap*[b]
 };
 
-// One wave = one workgroup = one 4 x 4 pixel block.  Lane layout outside the sweep: row = lane / 16 is a
-// pixel of the current pass (pass q serves block row q: pixel k = 4 q + row), j = lane % 16 carries the
-// taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes reduce inside 16-lane rows with DPP only.
-template <int R, int KS, typename T>
-__global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p) {
+// One wave = one workgroup = a block of MT 4 x 4 pixel sub-blocks side by side (4 rows x 4 MT columns).  Every B
+// fragment (16 window positions x all channels) fetched by the sweep feeds MT MFMA row tiles, and the union window of
+// a 4 x 8 block is barely larger than that of a 4 x 4 one (the tap boxes are ~16 x 16 either way): MT = 2 moves
+// 28 positions per pixel-level through L2 -> CU instead of 47.  The price is LDS: 16.6 KB of patches per sub-block,
+// i.e. 4 waves per CU (one per SIMD) at MT = 2 against 9 at MT = 1 — which costs more than the traffic saves (see
+// launch_mfma below), so MT = 1 is the default and MT = 2 is kept for A/B.
+// Lane layout outside the sweep: row = lane / 16 is a pixel of the current pass (pass (m, q) serves row q of sub-block
+// m: pixel column 4 m + row), j = lane % 16 carries the taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes
+// reduce inside 16-lane rows with DPP only.
+template <int R, int KS, typename T, int MT>
+__global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(const MmParams p) {
   typedef typename MmT<T>::frag frag;
   constexpr int CPS = MmT<T>::CPS, EPL = MmT<T>::EPL;
   constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
@@ -144,9 +151,11 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
   constexpr int CEN = R * RD + R;      // centre tap
   constexpr int MM_PF = KS <= 4 ? 4 : 2;  // position groups in flight (16 bytes x KS per lane each)
   static_assert(sizeof(frag) == 16, "one 16-byte load per lane and k-step");
+  constexpr int NP = MM_BP * MT;        // pixels of the block
+  constexpr int MM_OUTP = mm_outp(MT);
   extern __shared__ float smem[];
-  float* const patch = smem;                                          // [16][MM_PP]
-  int* const pbox = reinterpret_cast<int*>(smem + MM_BP * MM_PP);     // [16][xlo,ylo,bw,bh]
+  float* const patch = smem;                                          // [NP][MM_PP]
+  int* const pbox = reinterpret_cast<int*>(smem + NP * MM_PP);        // [NP][xlo,ylo,bw,bh]
   const int lane = threadIdx.x;
   const int lx = lane & 15, lg = lane >> 4;
   const int B = p.B, S = p.S, H1 = p.H1, W1 = p.W1, blocks_x = p.blocks_x;
@@ -186,16 +195,16 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
 
   MM_STAMP(0);
   // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested first, consumed by the sweep
-  frag a[KS];
-  {
-    int h1 = by * 4 + (lx >> 2), w1 = bx * 4 + (lx & 3);
+  frag a[MT][KS];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    int h1 = by * 4 + (lx >> 2), w1 = (bx * MT + m) * 4 + (lx & 3);
     h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
     const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
 #pragma unroll
-    for (int s = 0; s < KS; s++) a[s] = *reinterpret_cast<const frag*>(ap + CPS * s);
+    for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
   }
   // ---- phase 0: sample positions and tap boxes (4 pixels per pass, one per lane row) ----
-  const int w1r = bx * 4 + lg;  // this lane row's pixel column
   int tix[TI], tiy[TI];         // offset / output index [ix][iy] of this lane's tap slots
 #pragma unroll
   for (int i = 0; i < TI; i++) {
@@ -203,66 +212,72 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
     tix[i] = t / RD;
     tiy[i] = t - tix[i] * RD;
   }
-  float2 cvv[4], o0[4][TI];
+  float2 cvv[MT][4], o0[MT][4][TI];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int h1 = by * 4 + q;
-    const bool pv = h1 < H1 && w1r < W1;
-    const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
-    cvv[q] = cbase[pix];
-    cvv[q].x *= cscale; cvv[q].y *= cscale;
-#pragma unroll
-    for (int i = 0; i < TI; i++) {
-      const int t = lx + 16 * i;
-      o0[q][i] = make_float2(0.f, 0.f);
-      if (obase && pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
-    }
-  }
-  if (obase) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
+  for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int h1 = by * 4 + q;
-      constexpr int ci = CEN / 16;
-      if (lx == CEN % 16 && h1 < H1 && w1r < W1) {
-        if ((__builtin_bit_cast(unsigned, o0[q][ci].x) | __builtin_bit_cast(unsigned, o0[q][ci].y)) != 0u)
-          reinterpret_cast<float2*>(obase + ((size_t)h1 * W1 + w1r) * NT * 2)[CEN] = make_float2(0.f, 0.f);
-        o0[q][ci] = make_float2(0.f, 0.f);
+      const int h1 = by * 4 + q, w1r = (bx * MT + m) * 4 + lg;  // this lane row's pixel
+      const bool pv = h1 < H1 && w1r < W1;
+      const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
+      cvv[m][q] = cbase[pix];
+      cvv[m][q].x *= cscale; cvv[m][q].y *= cscale;
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const int t = lx + 16 * i;
+        o0[m][q][i] = make_float2(0.f, 0.f);
+        if (obase && pv && t < NT) o0[m][q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
       }
     }
+  if (obase) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h1 = by * 4 + q, w1r = (bx * MT + m) * 4 + lg;
+        constexpr int ci = CEN / 16;
+        if (lx == CEN % 16 && h1 < H1 && w1r < W1) {
+          if ((__builtin_bit_cast(unsigned, o0[m][q][ci].x) | __builtin_bit_cast(unsigned, o0[m][q][ci].y)) != 0u)
+            reinterpret_cast<float2*>(obase + ((size_t)h1 * W1 + w1r) * NT * 2)[CEN] = make_float2(0.f, 0.f);
+          o0[m][q][ci] = make_float2(0.f, 0.f);
+        }
+      }
   }
-  int blo[4], bwh[4];  // per pass, row-uniform: packed (xlo, ylo); bw | bh << 8 (0 = no patch) | fallback << 16
+  int blo[MT][4], bwh[MT][4];  // per pass, row-uniform: packed (xlo, ylo); bw | bh << 8 (0 = no patch) | fallback << 16
   int ulo = 0x7fff7fff, uhi = (int)0x80008000;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int h1 = by * 4 + q;
-    const bool pv = h1 < H1 && w1r < W1;
-    int lo = 0x7fff7fff, hi = (int)0x80008000;
+  for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int i = 0; i < TI; i++) {
-      const float xs = cvv[q].x + o0[q][i].x, ys = cvv[q].y + o0[q][i].y;  // :82-83
-      const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
-      const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
-      const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
-      const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
-      lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
-      hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+    for (int q = 0; q < 4; q++) {
+      const int h1 = by * 4 + q, w1r = (bx * MT + m) * 4 + lg;
+      const bool pv = h1 < H1 && w1r < W1;
+      int lo = 0x7fff7fff, hi = (int)0x80008000;
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;  // :82-83
+        const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
+        const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
+        const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
+        const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
+        lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
+        hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+      }
+      lo = row_pk_reduce<true>(lo);
+      hi = row_pk_reduce<false>(hi);
+      const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
+      const bool any = xhi >= xlo && yhi >= ylo;
+      const bool boxed = any && xhi - xlo < MM_BOX && yhi - ylo < MM_BOX;
+      ulo = boxed ? pk_min(ulo, lo) : ulo;
+      uhi = boxed ? pk_max(uhi, hi) : uhi;
+      blo[m][q] = lo;
+      bwh[m][q] = boxed ? (xhi - xlo + 1) | ((yhi - ylo + 1) << 8) : (any ? 1 << 16 : 0);
+      if (lx == 0) {
+        int* pb = pbox + (m * MM_BP + q * 4 + lg) * 4;
+        pb[0] = xlo; pb[1] = ylo;
+        pb[2] = boxed ? xhi - xlo + 1 : 0;
+        pb[3] = boxed ? yhi - ylo + 1 : 0;
+      }
     }
-    lo = row_pk_reduce<true>(lo);
-    hi = row_pk_reduce<false>(hi);
-    const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
-    const bool any = xhi >= xlo && yhi >= ylo;
-    const bool boxed = any && xhi - xlo < MM_BOX && yhi - ylo < MM_BOX;
-    ulo = boxed ? pk_min(ulo, lo) : ulo;
-    uhi = boxed ? pk_max(uhi, hi) : uhi;
-    blo[q] = lo;
-    bwh[q] = boxed ? (xhi - xlo + 1) | ((yhi - ylo + 1) << 8) : (any ? 1 << 16 : 0);
-    if (lx == 0) {
-      int* pb = pbox + (q * 4 + lg) * 4;
-      pb[0] = xlo; pb[1] = ylo;
-      pb[2] = boxed ? xhi - xlo + 1 : 0;
-      pb[3] = boxed ? yhi - ylo + 1 : 0;
-    }
-  }
   // union over the four lane rows = the block window
   ulo = pk_min(pk_min(__builtin_amdgcn_readlane(ulo, 0), __builtin_amdgcn_readlane(ulo, 16)),
                pk_min(__builtin_amdgcn_readlane(ulo, 32), __builtin_amdgcn_readlane(ulo, 48)));
@@ -277,16 +292,18 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
 
   // ---- phase 1: sweep the block window with the matrix cores, scatter into the patches ----
   if (UX1 >= UX0 && UY1 >= UY0) {
-    // result register r of lane (lg, lx) is pixel 4*lg + r at window position gx0 + lx
-    int sbase[4], sxv[4], sylo[4], sbw[4], sbh[4];
+    // result register r of sub-block m, lane (lg, lx) is pixel 4*lg + r of that sub-block at window position gx0 + lx
+    int sbase[MT][4], sxv[MT][4], sylo[MT][4], sbw[MT][4], sbh[MT][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int p = lg * 4 + r;
-      const int xlo = pbox[p * 4 + 0], ylo = pbox[p * 4 + 1];
-      sbw[r] = pbox[p * 4 + 2]; sbh[r] = pbox[p * 4 + 3];
-      sxv[r] = lx - xlo; sylo[r] = ylo;
-      sbase[r] = p * MM_PP - ylo * MM_BOX - xlo + lx;
-    }
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int p = m * MM_BP + lg * 4 + r;
+        const int xlo = pbox[p * 4 + 0], ylo = pbox[p * 4 + 1];
+        sbw[m][r] = pbox[p * 4 + 2]; sbh[m][r] = pbox[p * 4 + 3];
+        sxv[m][r] = lx - xlo; sylo[m][r] = ylo;
+        sbase[m][r] = p * MM_PP - ylo * MM_BOX - xlo + lx;
+      }
     const int ngx = (UX1 - UX0 + MM_BOX) >> 4;  // groups of 16 positions per window row
     const int nit = ngx * (UY1 - UY0 + 1);
     auto bptr = [&](int y, int gx0) {
@@ -315,9 +332,13 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
 #pragma unroll
       for (int j = 0; j < MM_PF; j++) {
         if (it + j < nit) {  // wave-uniform
-          f32x4v d = {0.f, 0.f, 0.f, 0.f};
+          f32x4v d[MT];
 #pragma unroll
-          for (int s = 0; s < KS; s++) d = MmT<T>::mma(a[s], bq[j][s], d);
+          for (int m = 0; m < MT; m++) {
+            d[m] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; s++) d[m] = MmT<T>::mma(a[m][s], bq[j][s], d[m]);
+          }
           if (it + j + MM_PF < nit) {
             const T* p = bptr(yl, gxl);
 #pragma unroll
@@ -327,10 +348,12 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
           }
           const int yg = y * MM_BOX + gx0;
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const unsigned qx = (unsigned)(gx0 + sxv[r]), qy = (unsigned)(y - sylo[r]);
-            if (qx < (unsigned)sbw[r] && qy < (unsigned)sbh[r]) patch[sbase[r] + yg] = d[r];
-          }
+          for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const unsigned qx = (unsigned)(gx0 + sxv[m][r]), qy = (unsigned)(y - sylo[m][r]);
+              if (qx < (unsigned)sbw[m][r] && qy < (unsigned)sbh[m][r]) patch[sbase[m][r] + yg] = d[m][r];
+            }
           gx0 += 16;
           if (gx0 > UX1) { gx0 = UX0; y++; }
         }
@@ -353,58 +376,64 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
       tiy[i] = t - tix[i] * RD;
     }
   }
-  float res[4][TI];
+  float res[MT][4][TI];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int h1 = by * 4 + q;
-    const bool pv = h1 < H1 && w1r < W1;
-    const int xlo = pk_lo(blo[q]), ylo = pk_hi(blo[q]);
-    const bool has_patch = (bwh[q] & 0xff) != 0, fallback = (bwh[q] >> 16) != 0;
-    const float* const Dp = patch + (q * 4 + lg) * MM_PP;
+  for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int i = 0; i < TI; i++) {
-      const bool tv = pv && lx + 16 * i < NT;
-      const float xs = cvv[q].x + o0[q][i].x, ys = cvv[q].y + o0[q][i].y;
-      const float fxs = floorf(xs), fys = floorf(ys);
-      const float dx = xs - fxs, dy = ys - fys;  // :87-88
-      const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
-      const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
-      const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
-      float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-      if (tv && has_patch) {
-        const float* D = Dp + (h2 - ylo) * MM_BOX + (w2 - xlo);
-        if (b11) q11 = D[0];
-        if (b21) q21 = D[1];
-        if (b12) q12 = D[MM_BOX];
-        if (b22) q22 = D[MM_BOX + 1];
-      } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
-        const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
-                                        (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0));
-        q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+    for (int q = 0; q < 4; q++) {
+      const int h1 = by * 4 + q, w1r = (bx * MT + m) * 4 + lg;
+      const bool pv = h1 < H1 && w1r < W1;
+      const int xlo = pk_lo(blo[m][q]), ylo = pk_hi(blo[m][q]);
+      const bool has_patch = (bwh[m][q] & 0xff) != 0, fallback = (bwh[m][q] >> 16) != 0;
+      const float* const Dp = patch + (m * MM_BP + q * 4 + lg) * MM_PP;
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const bool tv = pv && lx + 16 * i < NT;
+        const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;
+        const float fxs = floorf(xs), fys = floorf(ys);
+        const float dx = xs - fxs, dy = ys - fys;  // :87-88
+        const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
+        const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
+        const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
+        float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+        if (tv && has_patch) {
+          const float* D = Dp + (h2 - ylo) * MM_BOX + (w2 - xlo);
+          if (b11) q11 = D[0];
+          if (b21) q21 = D[1];
+          if (b12) q12 = D[MM_BOX];
+          if (b22) q22 = D[MM_BOX + 1];
+        } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
+          const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
+                                          (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0));
+          q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+        }
+        res[m][q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
       }
-      res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
     }
-  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   MM_STAMP(4);
 
-  // ---- write-out: corr[b][n][ix][iy][h1][w1]; the patch region becomes the [tap][pixel] transpose tile ----
+  // ---- write-out: corr[b][n][ix][iy][h1][w1]; the patch region becomes the [tap][pixel] transpose tile, pixel index
+  // inside a tap row = q * 4 MT + m * 4 + column: a block row is 4 MT consecutive floats ----
   float* const outt = patch;
 #pragma unroll
-  for (int q = 0; q < 4; q++)
+  for (int m = 0; m < MT; m++)
 #pragma unroll
-    for (int i = 0; i < TI; i++)
-      if (lx + 16 * i < NT) outt[(lx + 16 * i) * MM_OUTP + q * 4 + lg] = res[q][i];
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+        if (lx + 16 * i < NT) outt[(lx + 16 * i) * MM_OUTP + q * 4 * MT + m * 4 + lg] = res[m][q][i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float* const cb = p.corr + (((size_t)b * S + n) * p.L + lvl) * NT * HW1;
-  for (int idx = lane; idx < NT * 4; idx += kWave) {
-    const int t = idx >> 2, q = idx & 3;
-    const int h1 = by * 4 + q, w1 = bx * 4;
-    if (h1 >= H1) continue;
-    const float4 v = *reinterpret_cast<const float4*>(outt + t * MM_OUTP + q * 4);
+  for (int idx = lane; idx < NT * 4 * MT; idx += kWave) {
+    const int t = idx / (4 * MT), qm = idx - t * (4 * MT);
+    const int q = qm / MT, m = qm - q * MT;
+    const int h1 = by * 4 + q, w1 = (bx * MT + m) * 4;
+    if (h1 >= H1 || w1 >= W1) continue;
+    const float4 v = *reinterpret_cast<const float4*>(outt + t * MM_OUTP + q * 4 * MT + m * 4);
     float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
     if (p.vec_out) {
       *reinterpret_cast<float4*>(dst) = v;
@@ -418,11 +447,11 @@ __global__ __launch_bounds__(kWave, 2) void lowmem_mfma_kernel(const MmParams p)
   MM_STAMP(5);
 }
 
-template <int R, int KS, typename T>
-static int launch_mfma(MmParams p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)MM_LDS_FLOATS;
-  auto kern = lowmem_mfma_kernel<R, KS, T>;
-  p.blocks_x = (p.W1 + 3) / 4;
+template <int R, int KS, typename T, int MT>
+static int launch_mfma_mt(MmParams p, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)mm_lds_floats(MT);
+  auto kern = lowmem_mfma_kernel<R, KS, T, MT>;
+  p.blocks_x = (p.W1 + 4 * MT - 1) / (4 * MT);
   p.blocks_y = (p.H1 + 3) / 4;
   const int blocks = p.blocks_x * p.blocks_y;
   p.xcd_map = p.B >= 8 ? 1 : 0;
@@ -431,6 +460,17 @@ static int launch_mfma(MmParams p, hipStream_t st) {
   p.vec_out = (p.W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.corr) & 15) == 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)p.S), dim3(kWave), lds, st, p);
   return launch_status();
+}
+
+// LGU_LOWMEM_MT (debug / A-B only): pixel sub-blocks per wave, 1 (default) or 2.  Measured (tools/ab_lowmem.py,
+// profiles/r02_ab_lowmem_mt.jsonl, config 4 shapes): MT = 2 moves 1.7x fewer bytes from L2 and wins only at level 0
+// (108 vs 116 us); at 4 waves per CU the latency of the box and sampling phases is exposed and the coarse levels lose
+// (51 vs 37 us, 49 vs 32 us): 229 vs 220 us for the four levels in one launch.  The sweep's L2 traffic is therefore
+// not what bounds this kernel at 8-9 waves per CU; occupancy (LDS: 16.6 KB of patches per 16 pixels) is.
+template <int R, int KS, typename T>
+static int launch_mfma(const MmParams& p, hipStream_t st) {
+  if (env_int("LGU_LOWMEM_MT", 1) >= 2 && p.W1 > 4) return launch_mfma_mt<R, KS, T, 2>(p, st);
+  return launch_mfma_mt<R, KS, T, 1>(p, st);
 }
 
 template <typename T>
