@@ -3,15 +3,18 @@ torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in CPU tests
 
 The reference has no multi-GPU path; this is the new design of
 SURVEY.md §8(e).  Factor-graph edges are independent units for every operator of the hot
-path, so they are partitioned with NO data-path collective; the one real exchange of an
-update step is the all-gather of the per-edge `target` / `weight` (E,ht,wd,2) that dense
-bundle adjustment consumes (reference factor_graph.py:290-300).
+path, so they are partitioned with NO data-path collective; the real exchanges of an
+update step are, before dense bundle adjustment (reference factor_graph.py:286-300):
+  * per EDGE   `target` / `weight` (E,ht,wd,2)           — factor_graph.py:290-291,295-296
+  * per SOURCE FRAME `damping` (ht,wd)                    — factor_graph.py:292,294
+  * per SOURCE FRAME `upmask` (8*8*9,ht,wd) when upsampling — factor_graph.py:286-287
 
 Backend (low-memory) path: edges are sharded by the reference's own source-frame chunks
-(factor_graph.py:272-276: all edges with ii in [i, i+8)), dealt round-robin to ranks, so
-that every chunk a rank processes is identical to a chunk of the single-GPU run — which
-keeps lowMem_defSample's `offset[b*n]` quirk (it reads the chunk's FIRST edge's offsets)
-bit-compatible — and per-edge GRU state stays on its owner across steps.
+(factor_graph.py:272-276: for i in range(0, jj.max()+1, 8): edges with ii in [i, i+8)),
+dealt round-robin to ranks, so that every chunk a rank processes is identical to a chunk
+of the single-GPU run — which keeps lowMem_defSample's `offset[b*n]` quirk (it reads the
+chunk's FIRST edge's offsets) bit-compatible — per-edge GRU state stays on its owner
+across steps, and every source frame (its damping, its upmask) has exactly one owner.
 """
 import torch
 import torch.distributed as dist
@@ -24,18 +27,22 @@ def balanced_shard(n_edges, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def chunk_shards(ii, world, chunk=8):
+def chunk_shards(ii, world, chunk=8, jj=None):
     """Round-robin assignment of source-frame chunks to ranks.
 
-    ii: 1-D integer tensor of edge source frames.  Returns a list (one per rank) of lists of
-    index tensors; each index tensor selects the edges of one chunk `ii in [i, i+chunk)`, in
-    the reference's iteration order (factor_graph.py:272-276).  Empty chunks are skipped.
+    ii (and jj): 1-D integer tensors of edge source (target) frames.  Returns a list (one per rank) of
+    lists of index tensors; each index tensor selects the edges of one chunk `ii in [i, i+chunk)`,
+    in the reference's iteration order.  The loop bound is the reference's, `range(0, jj.max()+1,
+    chunk)` (factor_graph.py:273): edges whose source frame lies beyond the last chunk that bound
+    produces are processed by NO chunk there, and by none here (ShardedEdgeSet.unprocessed).  With
+    jj=None the bound is ii.max()+1 (every edge is in some chunk).  Empty chunks are skipped.
     """
     shards = [[] for _ in range(world)]
     if ii.numel() == 0:
         return shards
+    bound = int(jj.max()) + 1 if jj is not None else int(ii.max()) + 1
     k = 0
-    for i in range(0, int(ii.max()) + 1, chunk):
+    for i in range(0, bound, chunk):
         idx = torch.nonzero((ii >= i) & (ii < i + chunk), as_tuple=False).flatten()
         if idx.numel() == 0:
             continue
@@ -44,41 +51,89 @@ def chunk_shards(ii, world, chunk=8):
     return shards
 
 
-class EdgeExchange:
-    """All-gather of per-edge tensors with uneven edge counts per rank.
+def _flat_all_gather(group):
+    """Which all-gather form this process group gets, decided ONCE from the backend's name — never by trying one
+    collective and falling back to another (if only some ranks raised, the ranks would issue mismatched collectives
+    and hang).  RCCL: the flat form (one contiguous receive buffer).  Anything else (gloo in the CPU tests): the list
+    form, which every backend implements."""
+    return dist.get_backend(group) == "nccl"
 
-    counts[r] = number of edges owned by rank r (known to every rank: the partition is a
-    pure function of the edge list).  `gather(x)` takes this rank's (counts[rank], ...) tensor
-    and returns the (sum(counts), ...) tensor in rank order on every rank.  One collective
-    per call: shards are padded to max(counts) so that all_gather_into_tensor applies.
+
+class RowExchange:
+    """All-gather of row-indexed tensors with uneven row counts per rank, returned in a caller-given global order.
+
+    counts[r] = rows owned by rank r; ids[r] = their global row ids (both known to every rank: the partition is a pure
+    function of the edge list).  `gather(x)` takes this rank's (counts[rank], ...) tensor, rows in ids[rank] order.
+    One collective per call (shards padded to max(counts)); the received (world, cmax, ...) buffer is read ONCE, through
+    a precomputed index, into its destination:
+      gather(x)            -> (n_global, ...) tensor, row g = the row with global id g (ids must then cover 0..n-1)
+      gather(x, out=buf)   -> buf[ids] = rows (rows no rank owns keep their previous value); returns buf
     """
 
-    def __init__(self, counts, group=None):
-        self.counts = [int(c) for c in counts]
+    def __init__(self, ids, n_global, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if len(self.counts) != self.world:
-            raise ValueError("need one edge count per rank")
+        if len(ids) != self.world:
+            raise ValueError("need one id tensor per rank")
+        self.ids = [i.long() for i in ids]
+        self.counts = [int(i.numel()) for i in ids]
+        self.n_global = int(n_global)
         self.cmax = max(self.counts) if self.counts else 0
+        self.flat = _flat_all_gather(group) if dist.is_initialized() and self.world > 1 else True
+        dev = ids[0].device if ids else torch.device("cpu")
+        self.all_ids = torch.cat(self.ids) if ids else torch.zeros(0, dtype=torch.long, device=dev)
+        # position of every owned row in the padded receive buffer, in all_ids order
+        self.src = torch.cat([r * self.cmax + torch.arange(c, device=dev) for r, c in enumerate(self.counts)]) \
+            if ids else self.all_ids
+        self.complete = self.all_ids.numel() == self.n_global and \
+            bool((torch.sort(self.all_ids).values == torch.arange(self.n_global, device=dev)).all())
+        self.src_by_id = None
+        if self.complete:  # receive-buffer position of global row g
+            self.src_by_id = torch.empty_like(self.src)
+            self.src_by_id[self.all_ids] = self.src
+        self._dev = {}
 
-    def gather(self, x):
+    def _index(self, dev):
+        """The three index tensors on the data's device (uploaded once per device, not per call)."""
+        if dev not in self._dev:
+            self._dev[dev] = tuple(t.to(dev) if t is not None else None for t in (self.all_ids, self.src, self.src_by_id))
+        return self._dev[dev]
+
+    def gather(self, x, out=None):
         if x.shape[0] != self.counts[self.rank]:
-            raise ValueError("rank %d owns %d edges, got %d" % (self.rank, self.counts[self.rank], x.shape[0]))
-        if self.world == 1:
-            return x
+            raise ValueError("rank %d owns %d rows, got %d" % (self.rank, self.counts[self.rank], x.shape[0]))
+        if out is None and not self.complete:
+            raise ValueError("rows without an owner: pass out= (they keep their previous value there)")
         tail = tuple(x.shape[1:])
-        pad = x.new_zeros((self.cmax,) + tail)
-        pad[: x.shape[0]] = x
-        out = x.new_empty((self.world * self.cmax,) + tail)
-        try:
-            dist.all_gather_into_tensor(out, pad.contiguous(), group=self.group)
-        except (RuntimeError, NotImplementedError):  # backend without the flat variant
-            parts = [x.new_empty((self.cmax,) + tail) for _ in range(self.world)]
-            dist.all_gather(parts, pad.contiguous(), group=self.group)
-            out = torch.cat(parts, 0)
-        out = out.view((self.world, self.cmax) + tail)
-        return torch.cat([out[r, : self.counts[r]] for r in range(self.world)], 0)
+        if self.world == 1:
+            recv = x
+        else:
+            pad = x.new_empty((self.cmax,) + tail)
+            pad[: x.shape[0]] = x
+            if self.flat:
+                recv = x.new_empty((self.world * self.cmax,) + tail)
+                dist.all_gather_into_tensor(recv, pad, group=self.group)
+            else:
+                parts = [x.new_empty((self.cmax,) + tail) for _ in range(self.world)]
+                dist.all_gather(parts, pad, group=self.group)
+                recv = torch.cat(parts, 0)
+        all_ids, src, src_by_id = self._index(recv.device)
+        if out is None:
+            return recv.index_select(0, src_by_id)
+        out.index_copy_(0, all_ids, recv.index_select(0, src))
+        return out
+
+
+class EdgeExchange(RowExchange):
+    """All-gather of per-edge tensors in RANK order (rank 0's edges, then rank 1's, ...): counts[r] = edges of rank r."""
+
+    def __init__(self, counts, group=None):
+        counts = [int(c) for c in counts]
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        super().__init__([torch.arange(offs[r], offs[r + 1]) for r in range(len(counts))], offs[-1], group)
 
 
 def sharded_pyramid_sample(block_call, coords, rank, world, exchange=None):
@@ -99,26 +154,34 @@ class ShardedEdgeSet:
 
     The partition is a pure function of the edge list, so every rank builds the same object:
     `chunks[r]` = the source-frame chunks (index tensors into the edge list) rank r processes,
-    `owned[r]` = their concatenation.  `gather(x_local)` all-gathers a per-edge tensor given in
-    this rank's `owned` order and returns it in the ORIGINAL edge order on every rank — what
-    dense BA consumes (reference factor_graph.py:290-300).
+    `owned[r]` = their concatenation, `frames[r]` = the source frames of those chunks (sorted: a
+    chunk is a range of source frames, so every frame has one owner), `unprocessed` = edges no chunk
+    of the reference's loop covers (they keep their previous target / weight, as in the reference).
+      gather(x_local[, out])         per-edge tensor in this rank's `owned` order -> ORIGINAL edge order on every rank
+      gather_frames(x_local, out)    per-source-frame tensor in this rank's `frames` order -> out[frame] on every rank
+    — what dense BA consumes (reference factor_graph.py:290-300).
     """
 
-    def __init__(self, ii, rank=None, world=None, chunk=8, group=None):
+    def __init__(self, ii, rank=None, world=None, chunk=8, group=None, jj=None):
         if world is None:
             world = dist.get_world_size(group) if dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world = rank, world
-        self.chunks = chunk_shards(ii, world, chunk)
+        self.chunks = chunk_shards(ii, world, chunk, jj)
         dev = ii.device
         empty = torch.zeros(0, dtype=torch.long, device=dev)
         self.owned = [torch.cat(c) if len(c) else empty for c in self.chunks]
         self.counts = [int(o.numel()) for o in self.owned]
-        order = torch.cat(self.owned) if self.owned else empty   # edge ids in gathered (rank-major) order
-        self.inverse = torch.empty_like(order)
-        self.inverse[order] = torch.arange(order.numel(), device=dev)
-        self.exchange = EdgeExchange(self.counts, group) if (dist.is_initialized() or world == 1) else None
+        self.frames = [torch.cat([torch.unique(ii[idx]) for idx in c]) if len(c) else empty for c in self.chunks]
+        covered = torch.zeros(ii.numel(), dtype=torch.bool, device=dev)
+        for o in self.owned:
+            covered[o] = True
+        self.unprocessed = torch.nonzero(~covered, as_tuple=False).flatten()
+        live = dist.is_initialized() or world == 1
+        self.exchange = RowExchange(self.owned, ii.numel(), group) if live else None
+        nframes = int(ii.max()) + 1 if ii.numel() else 0
+        self.frame_exchange = RowExchange(self.frames, nframes, group) if live else None
 
     @property
     def my_chunks(self):
@@ -128,9 +191,15 @@ class ShardedEdgeSet:
     def my_edges(self):
         return self.owned[self.rank]
 
-    def gather(self, x_local):
-        allx = self.exchange.gather(x_local) if self.world > 1 else x_local
-        return allx[self.inverse.to(allx.device)]
+    @property
+    def my_frames(self):
+        return self.frames[self.rank]
+
+    def gather(self, x_local, out=None):
+        return self.exchange.gather(x_local, out)
+
+    def gather_frames(self, x_local, out):
+        return self.frame_exchange.gather(x_local, out)
 
 
 class ShardedAltCorr:
@@ -142,7 +211,7 @@ class ShardedAltCorr:
         from .corr import AltCorrBlock
         self.block = AltCorrBlock(ofsMap, ofs_residual, GA, fmaps)
         self.ii, self.jj, self.rig = ii, jj, rig
-        self.edges = ShardedEdgeSet(ii, rank, world, chunk, group)
+        self.edges = ShardedEdgeSet(ii, rank, world, chunk, group, jj=jj)
 
     def lookup(self, coords1):
         """coords1 (1,E,H,W,2) for ALL edges (replicated).  Yields (edge_index_tensor, corr (1,n,196,H,W))
@@ -152,14 +221,59 @@ class ShardedAltCorr:
             yield idx, self.block(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long())
 
 
+def sharded_update_step(edges, ii, chunk_fn, target, weight, damping, upmask=None):
+    """The chunk loop of update_lowmem (reference factor_graph.py:272-292) over this rank's chunks, then the exchanges
+    that make every rank's state whole again.
+
+    chunk_fn(idx, iis) -> (target (n,ht,wd,2), weight (n,ht,wd,2), damping (f,ht,wd)[, upmask (f,...)]) for the edges
+    `idx` of one chunk (iis = their source frames, f = torch.unique(iis).numel(), frames ascending) — the caller's
+    correlation lookup + update operator.  target / weight (E,ht,wd,2), damping (num_frames,ht,wd) and the optional
+    upmask (num_frames,...) are the replicated state tensors; on return they hold, on EVERY rank, what the single-GPU
+    loop leaves there: rows of processed edges / owned frames from their owner, everything else untouched.
+    Collectives: one all-gather each for target, weight, damping (and upmask) — issued by every rank, also by ranks
+    that own no chunk."""
+    t_loc, w_loc, d_loc, u_loc = [], [], [], []
+    for idx in edges.my_chunks:
+        r = chunk_fn(idx, ii[idx])
+        t_loc.append(r[0]); w_loc.append(r[1]); d_loc.append(r[2])
+        if upmask is not None:
+            u_loc.append(r[3])
+
+    def cat(parts, like):
+        return torch.cat(parts, 0) if parts else like.new_zeros((0,) + tuple(like.shape[1:]))
+
+    edges.gather(cat(t_loc, target), out=target)
+    edges.gather(cat(w_loc, weight), out=weight)
+    edges.gather_frames(cat(d_loc, damping), out=damping)
+    if upmask is not None:
+        edges.gather_frames(cat(u_loc, upmask), out=upmask)
+    return target, weight, damping, upmask
+
+
+def replicas_agree(*tensors, group=None):
+    """True when every rank holds bit-identical copies of the given tensors (compared through an fp64 checksum and
+    the element count: one small all-reduce).  The replicated BA of a sharded step silently diverges otherwise."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    sig = torch.stack([t.detach().double().sum() + 1e-3 * t.detach().double().abs().sum() + t.numel() for t in tensors])
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
+
+
 def sharded_ba(edges, target_local, weight_local, poses, disps, intrinsics, disps_sens, eta, ii, jj, t0, t1,
-               iterations, lm, ep, motion_only):
+               iterations, lm, ep, motion_only, check_replicas=False):
     """The dense-BA step of a sharded update (reference factor_graph.py:290-300 after update_lowmem's chunk loop):
     every rank contributes the `target` / `weight` (n_local,2,ht,wd) of the edges it owns (in `edges.my_edges`
     order); ONE all-gather each restores the full (E,2,ht,wd) tensors in the original edge order on every rank, and the
     bundle adjustment (lgu_slam_amd.ba.ba) then runs replicated — identical inputs, deterministic kernels, so every
-    rank holds the same updated `poses` / `disps` without a broadcast."""
+    rank holds the same updated `poses` / `disps` without a broadcast.  `eta` must be the replicated per-frame damping
+    (after ShardedEdgeSet.gather_frames / sharded_update_step); check_replicas=True verifies that and the gathered
+    tensors across ranks before the solve (one scalar all-reduce pair) and raises on a mismatch."""
     from . import ba as _ba
     target = edges.gather(target_local).contiguous()
     weight = edges.gather(weight_local).contiguous()
+    if check_replicas and not replicas_agree(eta, target, weight, poses, disps, group=edges.exchange.group):
+        raise RuntimeError("sharded_ba: replicated inputs differ across ranks (eta / target / weight / poses / disps)")
     return _ba.ba(poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only)

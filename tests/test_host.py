@@ -193,6 +193,97 @@ def test_sharded_edge_set_gloo_world2():
     assert all(ok for _, ok, _ in res) and sum(res[0][2]) == 14
 
 
+def _reference_chunk_loop(ii, jj, chunk_fn, target, weight, damping, upmask):
+    """The single-process loop of the reference (factor_graph.py:272-292), written out: what a sharded step must equal."""
+    for i in range(0, int(jj.max()) + 1, 8):
+        v = torch.nonzero((ii >= i) & (ii < i + 8)).flatten()
+        if v.numel() == 0:
+            continue
+        t, w, d, u = chunk_fn(v, ii[v])
+        target[v] = t
+        weight[v] = w
+        damping[torch.unique(ii[v])] = d
+        upmask[torch.unique(ii[v])] = u
+    return target, weight, damping, upmask
+
+
+def _step_inputs():
+    g = torch.Generator().manual_seed(11)
+    # a non-bidirectional graph: the last source frames (40, 41) lie beyond the last chunk the reference's loop bound
+    # (jj.max() + 1 = 34 -> chunks start at 0, 8, 16, 24, 32) produces: processed by nobody, values stay
+    ii = torch.tensor([9, 0, 0, 17, 1, 3, 8, 9, 17, 30, 31, 40, 41, 2, 33, 12, 12])
+    jj = torch.tensor([8, 1, 2, 16, 0, 2, 9, 10, 18, 31, 30, 33, 33, 3, 32, 11, 13])
+    E, nf, ht, wd = ii.numel(), 42, 3, 4
+    state = [torch.randn(E, ht, wd, 2, generator=g), torch.randn(E, ht, wd, 2, generator=g),
+             torch.randn(nf, ht, wd, generator=g), torch.randn(nf, 5, ht, wd, generator=g)]
+
+    def chunk_fn(idx, iis):  # deterministic stand-in for lookup + update operator: depends on edge ids and frames only
+        fr = torch.unique(iis).float()
+        e = idx.float().view(-1, 1, 1, 1)
+        return (e + torch.zeros(idx.numel(), ht, wd, 2), 2 * e + torch.ones(idx.numel(), ht, wd, 2),
+                fr.view(-1, 1, 1) * 10 + torch.zeros(fr.numel(), ht, wd), fr.view(-1, 1, 1, 1) * 100 + torch.zeros(fr.numel(), 5, ht, wd))
+    return ii, jj, state, chunk_fn
+
+
+def _gloo_step_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import lgu_slam_amd
+    sh = lgu_slam_amd.sharded
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ii, jj, state, chunk_fn = _step_inputs()
+        want = _reference_chunk_loop(ii, jj, chunk_fn, *[t.clone() for t in state])
+        es = sh.ShardedEdgeSet(ii, jj=jj)
+        calls = []
+
+        def counted(idx, iis):
+            calls.append(idx.numel())
+            return chunk_fn(idx, iis)
+        got = sh.sharded_update_step(es, ii, counted, *[t.clone() for t in state])
+        ok = all(torch.equal(a, b) for a, b in zip(got, want))
+        # bookkeeping: every chunk on exactly one rank, frames owned once, the unprocessed edges are the reference's
+        agree = sh.replicas_agree(*got)
+        differ = sh.replicas_agree(got[0] + rank)  # rank-dependent tensor: must be reported as different
+        q.put((rank, ok, agree, differ, sum(calls), es.unprocessed.tolist(), [f.tolist() for f in es.frames], es.counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_step_gloo_world2():
+    """A complete sharded step (chunk loop on the owners, then the target / weight all-gathers by edge and the damping /
+    upmask all-gathers by source frame) leaves on BOTH ranks exactly what the reference's single-process loop leaves —
+    including the edges its jj.max() loop bound never processes."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_gloo_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, agree, differ, ncalls, unproc, frames, counts in res:
+        assert ok and agree and not differ
+        assert unproc == [11, 12]                      # ii = 40, 41 > last chunk of range(0, jj.max() + 1, 8)
+        assert sum(counts) == 15 and sorted(f for fr in frames for f in fr) == [0, 1, 2, 3, 8, 9, 12, 17, 30, 31, 33]
+    assert res[0][4] + res[1][4] == 15 and res[0][4] > 0 and res[1][4] > 0   # edges split over the two ranks
+
+
+def test_sharded_update_step_world1_equals_reference_loop(lgu):
+    ii, jj, state, chunk_fn = _step_inputs()
+    want = _reference_chunk_loop(ii, jj, chunk_fn, *[t.clone() for t in state])
+    es = lgu.sharded.ShardedEdgeSet(ii, rank=0, world=1, jj=jj)
+    got = lgu.sharded.sharded_update_step(es, ii, chunk_fn, *[t.clone() for t in state])
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(ValueError, match="without an owner"):
+        es.gather(state[0][es.my_edges])               # unprocessed edges: a destination buffer is required
+    # jj=None keeps the old bound (every edge in some chunk)
+    assert lgu.sharded.ShardedEdgeSet(ii, rank=0, world=1).unprocessed.numel() == 0
+
+
 def test_tiled_layout_host_logic(lgu):
     """Pure host side of the tiled slice layout: shapes, logical-size checks, and a numpy restatement of the
     address formula of include/lgu_corr.h (LGU_PYR_TILED) that round-trips every element of a padded slice."""
