@@ -383,6 +383,127 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+def backend_main(args, lgu, dev, rank, world, use_dist):
+    """BASELINE config 5: one global-BA iteration of update_lowmem (reference factor_graph.py:256-302) over a ~2000-edge
+    factor graph (200 keyframes of 60x80x128 half feature maps, edges between frames at most 5 apart = 1970 edges),
+    STRONG scaling: the graph is fixed and its source-frame chunks are dealt round-robin to the ranks.  One step =
+      lookups   this rank's chunks through AltCorrBlock (offset heads + fused low-memory lookup per chunk) and a
+                stand-in for the update operator (out of scope: target = coords + the first sample channels,
+                weight = sigmoid of the next ones, damping = per-source-frame mean)
+      exchange  all-gather of target / weight by edge and of damping by source frame (RCCL)
+      ba        dense bundle adjustment, 2 iterations, replicated on every rank (parity unpinned, experimental)
+    `value` = pixel·edges of the WHOLE graph per second of step time (max over ranks)."""
+    import torch.distributed as dist
+    sh = lgu.sharded
+    N, H, W, C, span = 200, 60, 80, 128, 5
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)  # the same graph and state on every rank (replicated, as the SLAM system holds them)
+
+    def randn(*s):
+        return torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+
+    ii_l = [i for i in range(N) for j in range(N) if i != j and abs(i - j) <= span]
+    jj_l = [j for i in range(N) for j in range(N) if i != j and abs(i - j) <= span]
+    ii, jj = torch.tensor(ii_l, device=dev), torch.tensor(jj_l, device=dev)
+    E = ii.numel()
+    fmaps = (randn(1, N, C, H, W) * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).to(dev)
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).to(dev)
+    with torch.no_grad():
+        for m in (ofsMap, ofsRes):
+            m.weight.copy_(randn(*m.weight.shape) * 0.02)
+            m.bias.copy_(randn(*m.bias.shape) * 0.02)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32),
+                            torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys], -1)
+    coords1 = (grid[None, None] + 2.0 * randn(1, E, H, W, 2)).contiguous()
+    sac = sh.ShardedAltCorr(ofsMap, ofsRes, None, fmaps, ii, jj, rig=1, rank=rank, world=world)
+    edges = sac.edges
+    target = coords1[0].clone()
+    weight = torch.zeros(E, H, W, 2, device=dev)
+    damping = torch.full((N, H, W), 1e-3, device=dev)
+    poses0 = torch.zeros(N, 7, device=dev)
+    poses0[:, 6] = 1
+    poses0[:, 0] = torch.arange(N, device=dev) * 0.05
+    disps0 = 0.3 + 0.7 * torch.rand(N, H, W, generator=g, device=dev)
+    intr = torch.tensor([60.0, 60.0, 40.0, 30.0], device=dev)
+    sens = torch.zeros_like(disps0)
+    poses, disps = poses0.clone(), disps0.clone()
+
+    def chunk_fn(idx, iis):
+        with torch.no_grad():
+            corr = sac.block(coords1[:, idx], iis, jjs_of(idx))[0]            # (n,196,H,W)
+            t = coords1[0, idx] + 0.05 * corr[:, 0:2].permute(0, 2, 3, 1)
+            w = torch.sigmoid(corr[:, 2:4].permute(0, 2, 3, 1))
+            fr, inv = torch.unique(iis, return_inverse=True)
+            d = torch.zeros(fr.numel(), H, W, device=dev).index_add_(0, inv, torch.sigmoid(corr[:, 4]))
+            d = d / torch.bincount(inv, minlength=fr.numel()).view(-1, 1, 1).float()
+        return t, w, d
+
+    def jjs_of(idx):
+        iis, jjs = ii[idx], jj[idx]
+        return jjs + (iis == jjs).long()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    phase = {"lookups": [], "exchange": [], "ba": []}
+
+    def step(record):
+        ev[0].record()
+        local = sh.run_chunks(edges, ii, chunk_fn)
+        ev[1].record()
+        sh.exchange_step(edges, local, target, weight, damping)
+        ev[2].record()
+        eta = (0.2 * damping[torch.unique(ii)] + 1e-7).contiguous()          # factor_graph.py:294
+        tg = target.permute(0, 3, 1, 2).contiguous()                          # :295-296
+        wg = weight.permute(0, 3, 1, 2).contiguous()
+        poses.copy_(poses0); disps.copy_(disps0)
+        lgu.ba.ba(poses, disps, intr, sens, tg, wg, eta, ii, jj, 1, N, 2, 1e-5, 1e-2, False)   # :299-300
+        ev[3].record()
+        if record:
+            ev[3].synchronize()
+            for k, name in enumerate(("lookups", "exchange", "ba")):
+                phase[name].append(ev[k].elapsed_time(ev[k + 1]))
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    wall = time.perf_counter() - t0
+    agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and world > 1 else True
+    if use_dist:
+        t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ph = float(t[0]), [float(x) for x in t[1:]]
+    else:
+        ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")]
+    if rank == 0:
+        units = E * H * W
+        emit({"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4; global BA step)",
+              "value": units / (wall / args.steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+              "vs_baseline": None, "dtype": "f16 features, f32 accumulate; f32/f64 BA", "data": "synthetic",
+              "config": {"workload": "BASELINE config 5: one update_lowmem iteration over a %d-edge graph (%d keyframes, 60x80x128 half "
+                                     "features), source-frame chunks of 8 dealt round-robin to %d rank(s); lookups + all-gathers + "
+                                     "replicated dense BA (2 iterations)" % (E, N, world),
+                         "edges_total": E, "edges_this_rank": int(edges.counts[rank]), "chunks_this_rank": len(edges.my_chunks),
+                         "units_per_step": units, "update_operator": "stand-in (out of scope)",
+                         "ba": "lgu_slam_amd.ba (experimental: parity unpinned)"},
+              "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2]},
+              "replicas_agree": agree,
+              "roofline": None, "cpu_baseline": None})
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def kernel_name(variant, probe, tiled, out_format):
     kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
              5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
@@ -417,9 +538,11 @@ def main():
     ap.add_argument("--edges", type=int, default=20, help="edges per GPU (BASELINE config 2: 20)")
     ap.add_argument("--probe", action="store_true", help="also time the level-1 uncertainty probe in the step")
     ap.add_argument("--variant", type=int, default=0, help="LGU_DEFCORR_VARIANT (A/B only)")
-    ap.add_argument("--workload", choices=["defcorr", "lowmem"], default="defcorr",
+    ap.add_argument("--workload", choices=["defcorr", "lowmem", "backend"], default="defcorr",
                     help="'defcorr' = BASELINE config 2 (the headline metric, stored-volume path); 'lowmem' = BASELINE config 4 "
-                         "(on-the-fly correlation from half feature maps at 60x80, the backend's path), reported in the same units")
+                         "(on-the-fly correlation from half feature maps at 60x80, the backend's path), reported in the same units; "
+                         "'backend' = BASELINE config 5 (one global-BA iteration over a 1970-edge graph, STRONG scaling over --gpus: "
+                         "shard lookups + all-gathers + replicated BA, per-phase breakdown; use --steps 10)")
     ap.add_argument("--layout", choices=["tiled", "rowmajor"], default="tiled",
                     help="storage of the pyramid the sampler reads: 'tiled' = the 4x8-tile slice layout CorrBlock keeps "
                          "its pyramid in (production), 'rowmajor' = the reference operator's layout (drop-in operator path)")
@@ -467,6 +590,8 @@ def main():
     ops = lgu_slam_amd.ops
     if args.workload == "lowmem":
         return lowmem_main(args, ops, dev, rank, world, use_dist)
+    if args.workload == "backend":
+        return backend_main(args, lgu_slam_amd, dev, rank, world, use_dist)
 
     E, H1, W1, L, R = args.edges, 48, 64, 4, 3
     cold = args.cache == "cold"

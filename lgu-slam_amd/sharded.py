@@ -221,23 +221,27 @@ class ShardedAltCorr:
             yield idx, self.block(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long())
 
 
-def sharded_update_step(edges, ii, chunk_fn, target, weight, damping, upmask=None):
-    """The chunk loop of update_lowmem (reference factor_graph.py:272-292) over this rank's chunks, then the exchanges
-    that make every rank's state whole again.
-
-    chunk_fn(idx, iis) -> (target (n,ht,wd,2), weight (n,ht,wd,2), damping (f,ht,wd)[, upmask (f,...)]) for the edges
-    `idx` of one chunk (iis = their source frames, f = torch.unique(iis).numel(), frames ascending) — the caller's
-    correlation lookup + update operator.  target / weight (E,ht,wd,2), damping (num_frames,ht,wd) and the optional
-    upmask (num_frames,...) are the replicated state tensors; on return they hold, on EVERY rank, what the single-GPU
-    loop leaves there: rows of processed edges / owned frames from their owner, everything else untouched.
-    Collectives: one all-gather each for target, weight, damping (and upmask) — issued by every rank, also by ranks
-    that own no chunk."""
+def run_chunks(edges, ii, chunk_fn, with_upmask=False):
+    """This rank's part of the chunk loop of update_lowmem (reference factor_graph.py:272-292): chunk_fn(idx, iis) ->
+    (target (n,ht,wd,2), weight (n,ht,wd,2), damping (f,ht,wd)[, upmask (f,...)]) for the edges `idx` of one chunk
+    (iis = their source frames, f = torch.unique(iis).numel(), frames ascending) — the caller's correlation lookup +
+    update operator.  Returns the per-chunk results as lists (target, weight, damping, upmask) in chunk order."""
     t_loc, w_loc, d_loc, u_loc = [], [], [], []
     for idx in edges.my_chunks:
         r = chunk_fn(idx, ii[idx])
         t_loc.append(r[0]); w_loc.append(r[1]); d_loc.append(r[2])
-        if upmask is not None:
+        if with_upmask:
             u_loc.append(r[3])
+    return t_loc, w_loc, d_loc, u_loc
+
+
+def exchange_step(edges, local, target, weight, damping, upmask=None):
+    """The exchanges that make every rank's state whole again after run_chunks: one all-gather each for target, weight
+    (by edge), damping and the optional upmask (by source frame) — issued by every rank, also by ranks that own no
+    chunk.  target / weight (E,ht,wd,2), damping (num_frames,ht,wd), upmask (num_frames,...) are the replicated state
+    tensors; on return they hold, on EVERY rank, what the single-GPU loop leaves there: rows of processed edges / owned
+    frames from their owner, everything else untouched."""
+    t_loc, w_loc, d_loc, u_loc = local
 
     def cat(parts, like):
         return torch.cat(parts, 0) if parts else like.new_zeros((0,) + tuple(like.shape[1:]))
@@ -248,6 +252,11 @@ def sharded_update_step(edges, ii, chunk_fn, target, weight, damping, upmask=Non
     if upmask is not None:
         edges.gather_frames(cat(u_loc, upmask), out=upmask)
     return target, weight, damping, upmask
+
+
+def sharded_update_step(edges, ii, chunk_fn, target, weight, damping, upmask=None):
+    """run_chunks + exchange_step: one sharded pass of update_lowmem's chunk loop."""
+    return exchange_step(edges, run_chunks(edges, ii, chunk_fn, upmask is not None), target, weight, damping, upmask)
 
 
 def replicas_agree(*tensors, group=None):
