@@ -209,6 +209,15 @@ int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const fl
 int lgu_volume_pyramid_h16(const float* means, const float* covs, const void* volume, float* const* levels, int L,
                            int E, int H1, int W1, int H2, int W2, int radius, int tiled, void* stream);
 
+/* The same builder with the determinant handed over: det (E*H1*W1) is what GaussianMask.forward computes as
+ * `det = cov[:,:,0] * cov[:,:,1]` (gaussianMask_cuda.py:79), fp32 or IEEE half (det_half != 0).  Inside the reference's
+ * autocast region (factor_graph.py:90) det IS a half tensor, and the denominator `6.28 * sqrt(det)` (:85) is rounded to half after
+ * the square root and after the product; a half det reproduces those roundings, an fp32 det is the fp32 evaluation
+ * (= lgu_volume_pyramid_f32 / _tiled_f32 / _h16, which form det = cov0 * cov1 themselves).  volume_half / tiled as above. */
+int lgu_volume_pyramid_det(const float* means, const float* covs, const void* det, int det_half, const void* volume,
+                           int volume_half, float* const* levels, int L, int E, int H1, int W1, int H2, int W2, int radius,
+                           int tiled, void* stream);
+
 /* Layout conversion of `nslices` slices of H2 x W2 floats: to_tiled != 0: row-major -> tiled, else tiled -> row-major
  * (padding elements of the tiled form are written as 0).  src and dst must not overlap. */
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream);

@@ -168,8 +168,11 @@ class CorrBlock:
             try:
                 # a half raw volume is converted by the builder's own load, not by a .float() pass
                 src = raw.contiguous() if raw.dtype == torch.float16 else raw.float().contiguous()
+                # det as the Gaussian head produced it: half inside autocast, where the reference's denominator
+                # 6.28 * sqrt(det) is rounded to half twice (gaussianMask_cuda.py:79-86 under factor_graph.py:90)
+                dd = det.contiguous() if det.dtype in (torch.float32, torch.float16) else det.float().contiguous()
                 self._adopt_store(ops.volume_pyramid(mean_n.float().contiguous(), cov.float().contiguous(), src, num_levels,
-                                                     GA.RADIUS, inplace=True, tiled=tiled))
+                                                     GA.RADIUS, inplace=True, tiled=tiled, det=dd))
                 self._tiled = tiled
             except _lib.UnsupportedShape:
                 self.corr_pyramid = None

@@ -149,6 +149,8 @@ struct VolPyrParams {
   const float* means;
   const float* covs;
   const void* vin;      // fp32, or half when the kernel's HALF_IN is set
+  const void* det;      // optional (npix): det the caller's Gaussian head produced (fp32, or half when det_half); null = cov0 * cov1
+  int det_half;
   float* out[VP_MAXL];  // out[0] may alias an fp32 vin
   size_t npix;
   int H2, W2, L, r;
@@ -171,7 +173,23 @@ __global__ __launch_bounds__(VP_THREADS) void volume_pyramid_kernel(const VolPyr
   const int H2 = p.H2, W2 = p.W2, HW2 = H2 * W2;
   const float mx = p.means[pix * 2 + 0], my = p.means[pix * 2 + 1];
   const float c1 = p.covs[pix * 2 + 0], c2 = p.covs[pix * 2 + 1];
-  const float den = 6.28f * sqrtf(c1 * c2);  // gaussianMask_cuda.py:79,85 (det = cov0*cov1)
+  // denominator = 6.28 * torch.sqrt(det) (gaussianMask_cuda.py:79,85; det = cov0*cov1).  Under autocast the reference's
+  // det is a HALF tensor (factor_graph.py:90 builds CorrBlock inside autocast): sqrt and the product with the Python
+  // scalar are then half kernels — evaluated in fp32, rounded to half after each — and the fp32 division promotes the
+  // rounded value back.  A half `det` reproduces exactly that; an fp32 `det` (or none) is the fp32 evaluation.
+  float den;
+  if (p.det && p.det_half) {
+    const _Float16 sq = (_Float16)sqrtf((float)static_cast<const _Float16*>(p.det)[pix]);
+    // torch's half multiply rounds the fp32 product to fp32 and THEN to half.  Left to itself the compiler fuses the
+    // product and the conversion into v_fma_mixlo_f16, which rounds the exact product once — different on ties
+    // (det = 4.203125: 2.05078125 * 6.28f is within 4e-7 of the midpoint of two halves).  The empty asm pins the
+    // fp32 product in a register.
+    float prod = (float)sq * 6.28f;
+    asm volatile("" : "+v"(prod));
+    den = (float)(_Float16)prod;
+  } else {
+    den = 6.28f * sqrtf(p.det ? static_cast<const float*>(p.det)[pix] : c1 * c2);
+  }
   const int cx = (int)floorf(mx), cy = (int)floorf(my);
   const int xa = cx - p.r, xb = cx + p.r, ya = cy - p.r, yb = cy + p.r;
   typedef _Float16 vp_half4 __attribute__((ext_vector_type(4)));
@@ -314,7 +332,7 @@ int lgu_gaussmask_bwd_f32(const float* means, const float* covs, const float* vo
 
 static int volume_pyramid_host(const float* means, const float* covs, const void* volume, float* const* levels, int L,
                                int E, int H1, int W1, int H2, int W2, int radius, bool tiled, void* stream,
-                               bool half_in = false) {
+                               bool half_in = false, const void* det = nullptr, bool det_half = false) {
   using namespace lgu;
   if (!means || !covs || !volume || !levels || L < 1 || L > VP_MAXL) return LGU_E_BADARG;
   if (E < 0 || H1 < 1 || W1 < 1 || H2 < 1 || W2 < 1 || radius < 0) return LGU_E_BADARG;
@@ -331,6 +349,7 @@ static int volume_pyramid_host(const float* means, const float* covs, const void
   if (E == 0) return LGU_OK;
   VolPyrParams p;
   p.means = means; p.covs = covs; p.vin = volume;
+  p.det = det; p.det_half = det_half ? 1 : 0;
   for (int l = 0; l < VP_MAXL; l++) p.out[l] = l < L ? levels[l] : nullptr;
   p.npix = (size_t)E * H1 * W1; p.H2 = H2; p.W2 = W2; p.L = L; p.r = radius;
   auto kern = half_in ? (tiled ? volume_pyramid_kernel<true, true> : volume_pyramid_kernel<false, true>)
@@ -357,6 +376,14 @@ int lgu_volume_pyramid_tiled_f32(const float* means, const float* covs, const fl
 int lgu_volume_pyramid_h16(const float* means, const float* covs, const void* volume, float* const* levels, int L,
                            int E, int H1, int W1, int H2, int W2, int radius, int tiled, void* stream) {
   return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, tiled != 0, stream, true);
+}
+
+int lgu_volume_pyramid_det(const float* means, const float* covs, const void* det, int det_half, const void* volume,
+                           int volume_half, float* const* levels, int L, int E, int H1, int W1, int H2, int W2, int radius,
+                           int tiled, void* stream) {
+  if (!det) return LGU_E_BADARG;
+  return volume_pyramid_host(means, covs, volume, levels, L, E, H1, W1, H2, W2, radius, tiled != 0, stream, volume_half != 0,
+                             det, det_half != 0);
 }
 
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream) {

@@ -398,14 +398,17 @@ def defcorr_pyramid_forward(volumes, coords, offsets, radius, probe=False, out=N
     return out
 
 
-def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, tiled=False):
+def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, tiled=False, det=None):
     """Fused volume post-processing of CorrBlock.__init__ (reference gaussianMask_cuda.py:84-86
     + corr.py:79-86): level0 = gaussianMask(means, covs, volume, radius) / (6.28*sqrt(det)) +
     volume, levels 1.. by 2x2 average pooling of the target dims — one pass over the volume.
     Returns the list of pyramid levels; with inplace=True level 0 reuses `volume`'s storage.
     tiled=True: the levels are written in the tiled slice layout (tiled_shape); same values.
     A HALF volume (the matmul of half feature maps) is converted by the kernel's own load — the levels are fp32 and
-    equal those of volume.float(); inplace is then ignored."""
+    equal those of volume.float(); inplace is then ignored.
+    det: the (E, H1*W1) determinant GaussianMask.gaussian_parameters returned, fp32 or half.  Inside autocast the
+    reference's det is half and its denominator `6.28 * torch.sqrt(det)` carries two half roundings (factor_graph.py:90,
+    gaussianMask_cuda.py:79-86); passing that det reproduces them.  None: det = cov0 * cov1 in fp32."""
     half_in = volume.dtype == torch.float16
     if half_in:
         _check(means, "means", covs, "covs")
@@ -429,6 +432,15 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     if E == 0:
         return levels
     lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
+    if det is not None:
+        if det.dtype not in (torch.float32, torch.float16) or not (det.is_cuda and det.is_contiguous()) or det.numel() != E * H1 * W1:
+            raise RuntimeError("det must be a contiguous fp32 or half CUDA tensor of E*H1*W1 elements")
+        with torch.cuda.device(volume.device):
+            rc = _lib.load().lgu_volume_pyramid_det(_ptr(means), _ptr(covs), _ptr(det), 1 if det.dtype == torch.float16 else 0,
+                                                    _ptr(volume), 1 if half_in else 0, lp, num_levels, E, H1, W1, H2, W2, radius,
+                                                    1 if tiled else 0, _stream(volume))
+        _lib.check(rc, "volume_pyramid")
+        return levels
     with torch.cuda.device(volume.device):
         if half_in:
             rc = _lib.load().lgu_volume_pyramid_h16(_ptr(means), _ptr(covs), _ptr(volume), lp, num_levels, E, H1, W1, H2, W2,

@@ -680,6 +680,49 @@ def test_corrblock_matches_reference_shaped_composition(lgu, oracle, tiled, monk
             assert np.abs(host(got)[0] - want).max() <= 2e-5, "call %d" % it
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiled", [True, False])
+def test_corrblock_under_autocast_matches_the_torch_composition_under_autocast(lgu, tiled, monkeypatch):
+    """The reference builds CorrBlock inside autocast (factor_graph.py:90 `add_factors`): GA's heads run in half, `det`
+    is a half tensor and `6.28 * torch.sqrt(det)` (gaussianMask_cuda.py:79-86) is rounded to half after the square root
+    and after the product.  The fused builder (ops.volume_pyramid with the det handed over) must give what the torch
+    composition GA.forward + avg_pool2d gives under the SAME autocast — not the fp32 evaluation of the denominator, which
+    is ~1e-3 relative off in the Gaussian term."""
+    monkeypatch.setattr(lgu.CorrBlock, "TILED_PYRAMID", tiled)
+    torch.manual_seed(5)
+    E, h, w = 2, 48, 64
+    dev_ = "cuda"
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    GA = lgu.GaussianMask(h, w).to(dev_)
+    torch.nn.init.normal_(GA.meanMap.weight, 0, 0.3)
+    f1 = (torch.randn(1, E, 128, h, w, device=dev_) * 0.5).half()
+    f2 = (torch.randn(1, E, 128, h, w, device=dev_) * 0.5).half()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        assert blk._store is not None and blk._tiled == tiled          # the fused builder ran
+        got = [lgu.ops.volume_retile(v.contiguous(), to_tiled=False, hw=blk._level_hw[i]) if tiled else v
+               for i, v in enumerate(blk.corr_pyramid)]
+        # the reference-shaped composition under the same autocast (torch ops + the gaussianMask operator, which the
+        # reference-build tests hold to the reference's kernel)
+        monkeypatch.setattr(lgu.gaussian_mask, "FUSED_PARAMS", False)
+        vol = lgu.CorrBlock.corr(f1, f2).view(E, h, w, h, w).float()
+        ref0, mean_ref, det_ref = GA(blk.t, vol)
+        assert det_ref.dtype == torch.float16                           # the premise: det is half in this context
+        lv = ref0.reshape(E * h * w, 1, h, w)
+        for i in range(4):
+            want = lv.view(E, h, w, h >> i, w >> i)
+            scale = float(want.abs().max())
+            assert float((got[i] - want).abs().max()) <= 1e-6 * max(scale, 1.0), "level %d" % i   # measured: 0.0
+            lv = torch.nn.functional.avg_pool2d(lv, 2, stride=2)
+        # and the fp32 evaluation of the denominator is measurably different here (what round 1 shipped)
+        fp32_den = lgu.ops.volume_pyramid(mean_ref.float().contiguous(),
+                                          (torch.sigmoid(lgu.gaussian_mask.per_Corr_Normalization(
+                                              GA.covMap(GA.mapA(blk.t)).view(E, h * w, 2), [1, 2])) * 5 + 0.05).view(E, h, w, 2).float().contiguous(),
+                                          vol.clone(), 1)[0]
+        assert float((fp32_den - ref0).abs().max()) > float((got[0] - ref0).abs().max())
+
+
 TILED_CASES = {
     # name: (seed, E, H1, W1, L, sigma, off_scale, dense)
     "cfg2_shape": (31, 2, 48, 64, 4, 3.0, 4.0, False),          # level 3 is 6x8: padded to 8x8 in the tiled form
