@@ -155,7 +155,9 @@ class CorrBlock:
         self.offset, self._zero_level = generate_offsets(ofsMap, ofs_residual, feats, num_levels)
 
         self.t = feats.permute(0, 2, 3, 1).contiguous()
-        needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(q.requires_grad for q in GA.parameters()))
+        # the offsets are part of the autograd graph when only the offset heads train (frozen fnet / GA)
+        needs_grad = torch.is_grad_enabled() and (feats.requires_grad or any(q.requires_grad for q in GA.parameters())
+                                                  or any(o.requires_grad for o in self.offset))
         self._store = None       # slot-indirected level buffers (inference), see _adopt_store
         self._pyr = None         # plain list of level tensors in edge order (training / fallback)
         self._tiled = False
@@ -247,9 +249,11 @@ class CorrBlock:
         coords_xy = coords.reshape(E, ht, wd, 2)   # as handed over: x, y interleaved (the fused kernel reads this form)
         coords = None                               # (E,2,ht,wd) planes, made only where an operator needs them
 
-        needs_grad = torch.is_grad_enabled() and self._store is None and (
-            any(v.requires_grad for v in self._pyr) or any(o.requires_grad for o in self.offset))
+        needs_grad = torch.is_grad_enabled() and (any(o.requires_grad for o in self.offset) or (
+            self._store is None and any(v.requires_grad for v in self._pyr)))
         if needs_grad:
+            if self._store is not None:   # an inference store with trainable offsets: leave it, the fused launch
+                self._to_reference_layout()   # returns no grad_fn and writes the offsets through raw pointers
             coords = coords_xy.permute(0, 3, 1, 2).contiguous()
             # training: reference-shaped composition through the autograd Functions.
             # Uncertainty probe on level 1; the mask is folded into offset[1] and PERSISTS

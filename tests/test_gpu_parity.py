@@ -723,6 +723,42 @@ def test_corrblock_under_autocast_matches_the_torch_composition_under_autocast(l
         assert float((fp32_den - ref0).abs().max()) > float((got[0] - ref0).abs().max())
 
 
+@pytest.mark.gpu
+def test_corrblock_routes_gradients_to_trainable_offset_heads(lgu):
+    """Fine-tuning only ofsMap / ofs_residual (frozen feature maps and GA): the lookup must stay on the autograd path —
+    the fused launch would return a tensor without grad_fn and scale the tracked offsets through raw pointers."""
+    torch.manual_seed(9)
+    E, h, w = 1, 24, 32
+    dev_ = "cuda"
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev_)
+    GA = lgu.GaussianMask(h, w).to(dev_)
+    for q in GA.parameters():
+        q.requires_grad_(False)
+    f1 = torch.randn(1, E, 128, h, w, device=dev_) * 0.5
+    f2 = torch.randn(1, E, 128, h, w, device=dev_) * 0.5
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev_).float(), torch.arange(w, device=dev_).float(), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None, None] + torch.randn(1, E, h, w, 2, device=dev_)
+    blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+    assert blk._store is None and blk.offset[0].requires_grad      # not the inference store
+    out, _, _ = blk(coords)
+    assert out.requires_grad and out.shape == (1, E, 196, h, w)
+    out.square().mean().backward()
+    assert ofsMap.weight.grad is not None and float(ofsMap.weight.grad.abs().max()) > 0
+    assert ofsRes.weight.grad is not None and float(ofsRes.weight.grad.abs().max()) > 0
+    # a block built for inference whose offsets are later made trainable leaves the store on its first tracked lookup
+    with torch.no_grad():
+        blk2 = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+    assert blk2._store is not None
+    blk2.offset[0] = blk2.offset[0].clone().requires_grad_(True)
+    out2, _, _ = blk2(coords)
+    assert out2.requires_grad and blk2._store is None
+    with torch.no_grad():                                           # same numbers as the inference lookup
+        blk3 = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        out3, _, _ = blk3(coords)
+    assert float((out2.detach() - out3).abs().max()) <= 2e-5
+
+
 TILED_CASES = {
     # name: (seed, E, H1, W1, L, sigma, off_scale, dense)
     "cfg2_shape": (31, 2, 48, 64, 4, 3.0, 4.0, False),          # level 3 is 6x8: padded to 8x8 in the tiled form
