@@ -41,6 +41,43 @@ def _check(*named):
             raise RuntimeError("expected scalar type Float but found %s (%s)" % (str(t.dtype).replace("torch.", ""), name))
 
 
+_TORCH_NAME = {torch.float32: "Float", torch.float16: "Half", torch.float64: "Double", torch.bfloat16: "BFloat16",
+               torch.int64: "Long", torch.int32: "Int"}
+
+
+def _via_float(fn, scalar_named, coords, tail, inout=()):
+    """Half / double operands of the volume-path operators.  The reference dispatches those kernels with
+    AT_DISPATCH_FLOATING_TYPES_AND_HALF on the first tensor's type (defCorrSample_kernel.cu:185,219;
+    corrSample_kernel.cu:158,189; gaussianAttn.cu:152,187): every scalar_t accessor must then have that dtype
+    ("expected scalar type Half but found Float") while `coords` stays a float accessor.  The HIP kernels are fp32, so
+    these dtypes are served through fp32 copies: computed in fp32 (the arithmetic of the float dispatch), results cast to
+    the operands' dtype, in-place side effects (centre zeroing) copied back.  Every reference call site passes float
+    (corr.py:30-31,64; gaussianMask_cuda.py:11-12) — this is interface completeness, not a fast path.
+    scalar_named = [t0, "name0", t1, "name1", ...] (t0 decides the dtype); inout = indices into the scalar tensors that
+    the operator modifies."""
+    ts, names = list(scalar_named[0::2]), list(scalar_named[1::2])
+    dt = ts[0].dtype
+    for t, n in zip(ts, names):
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % n)
+    if coords is not None:
+        if not coords.is_contiguous():
+            raise RuntimeError("coords must be contiguous")
+        if coords.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float but found %s" % _TORCH_NAME.get(coords.dtype, str(coords.dtype)))
+    for t, n in zip(ts, names):
+        if t.dtype != dt:
+            raise RuntimeError("expected scalar type %s but found %s" % (_TORCH_NAME.get(dt, str(dt)), _TORCH_NAME.get(t.dtype, str(t.dtype))))
+    f32 = [t.float() for t in ts]
+    outs = fn(*f32, *([coords] if coords is not None else []), *tail)
+    for i in inout:
+        ts[i].copy_(f32[i])
+    return [o.to(dt) for o in outs]
+
+
+_OTHER_FLOATS = (torch.float16, torch.float64)
+
+
 def _stream(t):
     return _vp(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -50,6 +87,9 @@ def _ptr(t):
 
 
 def defCorr_index_forward(volume, coords, offset, radius):
+    if volume.dtype in _OTHER_FLOATS:
+        return _via_float(lambda v, o, c, r: defCorr_index_forward(v, c, o, r), [volume, "volume", offset, "offset"], coords,
+                          (radius,), inout=(1,))
     _check(volume, "volume", coords, "coords", offset, "offset")
     E, H1, W1, H2, W2 = volume.shape
     rd = 2 * radius + 1
@@ -66,6 +106,9 @@ def defCorr_index_forward(volume, coords, offset, radius):
 
 
 def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
+    if volume.dtype in _OTHER_FLOATS:
+        return _via_float(lambda v, o, g, c, r: defCorr_index_backward(v, c, o, g, r),
+                          [volume, "volume", offset, "offset", corr_grad, "corr_grad"], coords, (radius,), inout=(1,))
     _check(volume, "volume", coords, "coords", offset, "offset", corr_grad, "corr_grad")
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
@@ -81,6 +124,8 @@ def defCorr_index_backward(volume, coords, offset, corr_grad, radius):
 
 
 def corr_index_forward(volume, coords, radius):
+    if volume.dtype in _OTHER_FLOATS:
+        return _via_float(lambda v, c, r: corr_index_forward(v, c, r), [volume, "volume"], coords, (radius,))
     _check(volume, "volume", coords, "coords")
     E, H1, W1, H2, W2 = volume.shape
     rd = 2 * radius + 1
@@ -97,6 +142,9 @@ def corr_index_forward(volume, coords, radius):
 
 
 def corr_index_backward(volume, coords, corr_grad, radius):
+    if volume.dtype in _OTHER_FLOATS:
+        return _via_float(lambda v, g, c, r: corr_index_backward(v, c, g, r), [volume, "volume", corr_grad, "corr_grad"], coords,
+                          (radius,))
     _check(volume, "volume", coords, "coords", corr_grad, "corr_grad")
     E, H1, W1, H2, W2 = volume.shape
     volume_grad = torch.zeros_like(volume)
@@ -110,6 +158,8 @@ def corr_index_backward(volume, coords, corr_grad, radius):
 
 
 def gaussianMask(means, covs, volume, radius):
+    if volume.dtype in _OTHER_FLOATS:   # gaussianAttn.cu:152 dispatches on volume; means / covs are scalar_t accessors too
+        return _via_float(lambda v, m, c, r: gaussianMask(m, c, v, r), [volume, "volume", means, "means", covs, "covs"], None, (radius,))
     _check(volume, "volume", means, "means", covs, "covs")
     E, H1, W1, H2, W2 = volume.shape
     volume1 = torch.empty_like(volume)
@@ -123,6 +173,9 @@ def gaussianMask(means, covs, volume, radius):
 
 
 def gaussianMask_backward(means, covs, volume, volume_grad, radius):
+    if volume.dtype in _OTHER_FLOATS:
+        return _via_float(lambda v, m, c, g, r: gaussianMask_backward(m, c, v, g, r),
+                          [volume, "volume", means, "means", covs, "covs", volume_grad, "volume_grad"], None, (radius,))
     _check(volume, "volume", means, "means", covs, "covs", volume_grad, "volume_grad")
     E, H1, W1, H2, W2 = volume.shape
     means_grad = torch.empty_like(means)

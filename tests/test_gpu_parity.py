@@ -759,6 +759,39 @@ def test_corrblock_routes_gradients_to_trainable_offset_heads(lgu):
     assert float((out2.detach() - out3).abs().max()) <= 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.float64])
+def test_volume_operators_accept_half_and_double(lgu, dt):
+    """The reference dispatches the volume-path kernels for half and double too (AT_DISPATCH_FLOATING_TYPES_AND_HALF);
+    here those dtypes run the fp32 kernels on fp32 copies: outputs = the float operator's outputs in the operands'
+    dtype, the centre-zeroing side effect lands in the caller's offset tensor."""
+    ops = lgu.ops
+    case = inputs.pyramid_case(77, 2, 12, 16, 1, 3)
+    vol = dev(case["volumes"][0]).to(dt)
+    coords = dev(case["coords"])
+    off = dev(case["offsets"][0]).to(dt)
+    assert float(off[:, :, :, 3, 3].abs().max()) > 0
+    off32 = off.float()
+    want, = ops.defCorr_index_forward(vol.float(), coords, off32, 3)
+    got, = ops.defCorr_index_forward(vol, coords, off, 3)
+    assert got.dtype == dt and torch.equal(got, want.to(dt))
+    assert float(off[:, :, :, 3, 3].abs().max()) == 0 and torch.equal(off, off32.to(dt))
+    g = torch.randn_like(want)
+    vg, og = ops.defCorr_index_backward(vol, coords, off, g.to(dt), 3)
+    vg32, og32 = ops.defCorr_index_backward(vol.float(), coords, off.float(), g.to(dt).float(), 3)
+    assert vg.dtype == dt and og.dtype == dt and torch.equal(vg, vg32.to(dt)) and torch.equal(og, og32.to(dt))
+    p1, = ops.corr_index_forward(vol, coords, 1)
+    assert torch.equal(p1, ops.corr_index_forward(vol.float(), coords, 1)[0].to(dt))
+    gv, = ops.corr_index_backward(vol, coords, torch.ones_like(p1), 1)
+    assert gv.dtype == dt and gv.shape == vol.shape
+    means = (coords.permute(0, 2, 3, 1).contiguous()).to(dt)
+    covs = (torch.rand_like(means.float()) * 3 + 0.5).to(dt)
+    m1, = ops.gaussianMask(means, covs, vol, 2)
+    assert m1.dtype == dt and torch.equal(m1, ops.gaussianMask(means.float(), covs.float(), vol.float(), 2)[0].to(dt))
+    mg, cg = ops.gaussianMask_backward(means, covs, vol, torch.ones_like(vol), 2)
+    assert mg.dtype == dt and cg.dtype == dt and mg.shape == means.shape
+
+
 TILED_CASES = {
     # name: (seed, E, H1, W1, L, sigma, off_scale, dense)
     "cfg2_shape": (31, 2, 48, 64, 4, 3.0, 4.0, False),          # level 3 is 6x8: padded to 8x8 in the tiled form

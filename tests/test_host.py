@@ -284,6 +284,25 @@ def test_sharded_update_step_world1_equals_reference_loop(lgu):
     assert lgu.sharded.ShardedEdgeSet(ii, rank=0, world=1).unprocessed.numel() == 0
 
 
+def test_volume_operator_dtype_dispatch_errors(lgu):
+    """Half / double volumes follow the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF rule: every scalar_t operand
+    has the volume's dtype, coords stays float (defCorrSample_kernel.cu:185-191) — checked before any device work."""
+    ops = lgu.ops
+    v = torch.zeros(1, 2, 2, 4, 4, dtype=torch.float16)
+    c = torch.zeros(1, 2, 2, 2)
+    o = torch.zeros(1, 2, 2, 3, 3, 2)
+    with pytest.raises(RuntimeError, match="expected scalar type Half but found Float"):
+        ops.defCorr_index_forward(v, c, o, 1)
+    with pytest.raises(RuntimeError, match="expected scalar type Float but found Double"):
+        ops.defCorr_index_forward(v, c.double(), o.half(), 1)
+    with pytest.raises(RuntimeError, match="expected scalar type Double but found Float"):
+        ops.gaussianMask(torch.zeros(1, 2, 2, 2), torch.ones(1, 2, 2, 2), v.double(), 1)
+    with pytest.raises(RuntimeError, match="offset must be contiguous"):
+        ops.defCorr_index_forward(v, c, o.half().transpose(1, 2), 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # dtypes consistent: reaches the fp32 operator, which needs a GPU
+        ops.corr_index_forward(v, c, 1)
+
+
 def test_tiled_layout_host_logic(lgu):
     """Pure host side of the tiled slice layout: shapes, logical-size checks, and a numpy restatement of the
     address formula of include/lgu_corr.h (LGU_PYR_TILED) that round-trips every element of a padded slice."""
