@@ -327,3 +327,132 @@ def test_device_cholesky_solve_against_numpy(lgu, P):
         rc = lib.lgu_ba_solve_f64(ctypes.c_void_p(big.data_ptr()), ctypes.c_void_p(torch.zeros(198, dtype=torch.float64, device="cuda").data_ptr()),
                                   ctypes.c_void_p(torch.zeros(33, 6, device="cuda").data_ptr()), 33, lm, ep, None)
         assert rc == lgu._lib.LGU_E_UNSUPPORTED
+
+
+# ---- independent check of the Jacobians: central finite differences of the projection ---------------------------------
+# Nothing below touches oracle/ba_oracle.py: the forward model (SE3 exponential, quaternion action on a homogeneous point
+# with disparity, pinhole projection) is written out here in fp64 from the geometry, and every output of the build kernel
+# (reference projective_transform_kernel, src/droid_kernels.cu:176-425) is rebuilt from numerical derivatives of it.
+
+def _fd_quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _fd_quat_rot(q, X):
+    x, y, z, w = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return X @ Rm.T
+
+
+def _fd_exp_se3(xi):
+    """exp of a twist (translation part first): rotation exp(phi), translation V(phi) tau."""
+    tau, phi = xi[:3], xi[3:]
+    th = np.linalg.norm(phi)
+    K = np.array([[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]])
+    if th < 1e-12:
+        V = np.eye(3) + 0.5 * K
+        q = np.concatenate([0.5 * phi, [1.0]])
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+        q = np.concatenate([np.sin(th / 2) * phi / th, [np.cos(th / 2)]])
+    return V @ tau, q / np.linalg.norm(q)
+
+
+def _fd_left_perturb(pose, xi):
+    """exp(xi) * pose for pose = (t, q xyzw), a world-to-camera transform acting as X -> R X + t."""
+    t, q = _fd_exp_se3(xi)
+    return np.concatenate([_fd_quat_rot(q, pose[None, :3])[0] + t, _fd_quat_mul(q, pose[3:])])
+
+
+def _fd_project(pi, pj, disp, intr, stereo):
+    """Pixels of frame i (disparity `disp` (H,W)) seen in frame j: (2,H,W).  G_ij = G_j G_i^-1 (fixed baseline if stereo)."""
+    fx, fy, cx, cy = intr
+    H, W = disp.shape
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    X = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], -1).reshape(-1, 3)
+    if stereo:
+        tij, qij = np.array([-0.1, 0.0, 0.0]), np.array([0.0, 0.0, 0.0, 1.0])
+    else:
+        qi_inv = pi[3:] * np.array([-1, -1, -1, 1.0])
+        qij = _fd_quat_mul(pj[3:], qi_inv)
+        tij = pj[:3] - _fd_quat_rot(qij, pi[None, :3])[0]
+    Xj = _fd_quat_rot(qij, X) + disp.reshape(-1, 1) * tij[None]
+    return np.stack([fx * Xj[:, 0] / Xj[:, 2] + cx, fy * Xj[:, 1] / Xj[:, 2] + cy]).reshape(2, H, W), Xj[:, 2].min()
+
+
+@pytest.mark.gpu
+def test_build_kernel_jacobians_match_finite_differences(lgu):
+    """Hs, vs, Eii, Eij, Cii, wi of lgu_ba_build_f32 against central finite differences of an independent fp64 forward
+    model — for a temporal edge, its reverse, and a stereo edge (ii == jj: fixed baseline, pose terms zeroed)."""
+    import torch
+    rng = np.random.default_rng(12)
+    N, H, W = 3, 10, 12
+    intr = np.array([18.0, 17.0, W / 2 - 0.3, H / 2 + 0.2])
+    poses = np.zeros((N, 7))
+    poses[:, 6] = 1
+    for k in range(1, N):
+        poses[k] = _fd_left_perturb(poses[k], np.concatenate([rng.standard_normal(3) * 0.2, rng.standard_normal(3) * 0.08]))
+    disps = 0.4 + 0.6 * rng.random((N, H, W))
+    ii, jj = np.array([0, 1, 2, 1]), np.array([1, 0, 1, 1])
+    E, HW = len(ii), H * W
+    targets = np.stack([_fd_project(poses[i], poses[j], disps[i], intr, i == j)[0] for i, j in zip(ii, jj)])
+    targets = targets + rng.standard_normal(targets.shape) * 0.7         # non-zero residuals
+    weights = rng.random((E, 2, H, W)) + 0.1
+
+    dev = "cuda"
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt).contiguous()  # noqa: E731
+    lib = lgu._lib.load()
+    Hs = torch.empty(4, E, 6, 6, device=dev)
+    vs = torch.empty(2, E, 6, device=dev)
+    Eii, Eij = torch.empty(E, 6, HW, device=dev), torch.empty(E, 6, HW, device=dev)
+    Cii, wi = torch.empty(E, HW, device=dev), torch.empty(E, HW, device=dev)
+    scratch = torch.empty(E * lib.lgu_ba_build_slices(E) * 90, device=dev)
+    args = [t(targets), t(weights), t(poses), t(disps), t(intr), t(ii, torch.int64), t(jj, torch.int64)]
+    vp = ctypes.c_void_p
+    rc = lib.lgu_ba_build_f32(*[vp(a.data_ptr()) for a in args], *[vp(a.data_ptr()) for a in (Hs, vs, Eii, Eij, Cii, wi, scratch)],
+                              E, H, W, vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    Hs, vs, Eii, Eij, Cii, wi = [a.double().cpu().numpy() for a in (Hs, vs, Eii, Eij, Cii, wi)]
+
+    h = 1e-5
+    for e, (i, j) in enumerate(zip(ii, jj)):
+        stereo = i == j
+        f0, zmin = _fd_project(poses[i], poses[j], disps[i], intr, stereo)
+        assert zmin > 0.3                                                    # every point in front of MIN_DEPTH
+        Ji, Jj = np.zeros((6, 2, HW)), np.zeros((6, 2, HW))
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = h
+            if not stereo:
+                Jj[k] = ((_fd_project(poses[i], _fd_left_perturb(poses[j], d), disps[i], intr, False)[0]
+                          - _fd_project(poses[i], _fd_left_perturb(poses[j], -d), disps[i], intr, False)[0]) / (2 * h)).reshape(2, HW)
+                Ji[k] = ((_fd_project(_fd_left_perturb(poses[i], d), poses[j], disps[i], intr, False)[0]
+                          - _fd_project(_fd_left_perturb(poses[i], -d), poses[j], disps[i], intr, False)[0]) / (2 * h)).reshape(2, HW)
+        Jz = ((_fd_project(poses[i], poses[j], disps[i] + h, intr, stereo)[0]
+               - _fd_project(poses[i], poses[j], disps[i] - h, intr, stereo)[0]) / (2 * h)).reshape(2, HW)
+        w = 0.001 * weights[e].reshape(2, HW)                                # the kernel's weight scale (:309-310)
+        r = (targets[e] - f0).reshape(2, HW)
+        wp = np.zeros_like(w) if stereo else w                               # pose terms of a stereo edge carry no weight (:331,:369)
+        want_v = [np.einsum("cp,cp,kcp->k", wp, r, J) for J in (Ji, Jj)]
+        want_H = [np.einsum("cp,kcp,lcp->kl", wp, A, B) for A, B in ((Ji, Ji), (Ji, Jj), (Jj, Ji), (Jj, Jj))]
+        want_E = [np.einsum("cp,cp,kcp->kp", wp, Jz, J) for J in (Ji, Jj)]
+        want_C = (w * Jz * Jz).sum(0)                                        # the depth terms keep the weight (:328-329)
+        want_w = (w * r * Jz).sum(0)
+
+        def close(got, want, what):
+            scale = max(np.abs(want).max(), 1e-6)
+            assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (what, e, np.abs(got - want).max(), scale)
+        for m in range(2):
+            close(vs[m, e], want_v[m], "vs[%d]" % m)
+        for m in range(4):
+            close(Hs[m, e], want_H[m], "Hs[%d]" % m)
+        close(Eii[e], want_E[0], "Eii")
+        close(Eij[e], want_E[1], "Eij")
+        close(Cii[e], want_C, "Cii")
+        close(wi[e], want_w, "wi")
