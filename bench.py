@@ -505,15 +505,20 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
 
 
 def kernel_name(variant, probe, tiled, out_format):
-    kname = {0: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>", 4: "lgu::defcorr_gather_kernel<3,%s,12,2,32,LAYOUT>",
-             5: "lgu::defcorr_gather_kernel<3,%s,12,2,16,LAYOUT>",
-             3: "lgu::defcorr_gather_kernel<3,%s,12,4,16,LAYOUT>", 1: "lgu::defcorr_pyr_kernel<3,%s,12>",
-             2: "lgu::defcorr_generic_kernel%s"}.get(variant, "?%s") % (("true" if probe else "false") if variant != 2 else "")
-    kname = kname.replace("LAYOUT", "true" if tiled else "false")
-    if "gather_kernel" in kname:  # trailing template argument = output form; channel-last forms run 8-pixel tiles
-        om = {"planar": 0, "nhwc": 1, "nhwc_f16": 2}[out_format]
-        kname = (kname.replace(",2,16,", ",2,8,") if om else kname)[:-1] + ",%d>" % om
-    return kname
+    """Name of the kernel a launch of this configuration runs (as rocprofv3 prints it, spaces removed)."""
+    b = lambda v: "true" if v else "false"  # noqa: E731
+    if variant == 0 and out_format == "planar":   # the production configuration: csrc/defcorr_lean.hip
+        return "lgu::lean::defcorr_lean_kernel<%s,%s>" % (b(probe), b(tiled))
+    if variant == 1:
+        return "lgu::defcorr_pyr_kernel<3,%s,12>" % b(probe)
+    if variant == 2:
+        return "lgu::defcorr_generic_kernel"
+    gp, tpx = {3: (4, 16), 4: (2, 32)}.get(variant, (2, 16))
+    om = {"planar": 0, "nhwc": 1, "nhwc_f16": 2}[out_format]
+    if om:
+        tpx = 8
+    pair = variant in (0, 7) and om == 0
+    return "lgu::defcorr_gather_kernel<3,%s,12,%d,%d,%s,%d,%s>" % (b(probe), gp, tpx, b(tiled), om, b(pair))
 
 
 def load_traffic(kname, cache, tiled):

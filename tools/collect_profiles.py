@@ -2,7 +2,7 @@
 """Turns the raw rocprofv3 output of tools/gpu_full_run.sh (gpurun_out/prof_{trace,fetch,write}[_rm], prof_lm) into the
 small tracked summaries under profiles/: kernel-stats CSVs (top rows), PMC traffic JSONs (with the gfx950
 FETCH_SIZE correction) for both pyramid layouts, the low-memory kernel trace, and one combined JSON with the bench
-lines and the reference comparison.  Usage: collect_profiles.py [tag]   (default r01)"""
+lines and the reference comparison.  Usage: collect_profiles.py [tag]   (default r02)"""
 import collections
 import csv
 import glob
@@ -11,7 +11,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -27,21 +27,22 @@ def rows(name, suffix):
 
 def layout_summary(sfx, layout):
     ks = rows("prof_trace" + sfx, "kernel_stats")
-    kern = [r for r in ks if "defcorr_gather" in r["Name"]][0]
+    kern = [r for r in ks if "defcorr_" in r["Name"]][0]
     kname = kern["Name"].replace("void ", "").split("(")[0].replace(", ", ",")
 
     def mean(name, ctr):
         v = [(float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-             for r in rows(name, "counter_collection") if "defcorr_gather" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+             for r in rows(name, "counter_collection") if "defcorr_" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
         return sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)
 
     f, fd, fn = mean("prof_fetch" + sfx, "FETCH_SIZE")
     w, wd, wn = mean("prof_write" + sfx, "WRITE_SIZE")
-    cmd = "python3 bench.py --steps %d --warmup %d --no-cpu --layout " + layout
+    cmd = "python3 bench.py --steps %d --warmup %d --no-cpu --no-extra --cache cold --layout " + layout
     traffic = {
         "kernel": kname,
         "pyramid_layout": layout,
-        "workload": "BASELINE config 2, E=20 (61440 units per launch)",
+        "cache": "cold",
+        "workload": "BASELINE config 2, E=20 (61440 units per launch), launches rotating over 4 disjoint input sets (cold cache)",
         "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- " + cmd % (20, 2),
                      "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- " + cmd % (20, 2),
                      "rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd % (200, 20)],
@@ -63,8 +64,8 @@ def layout_summary(sfx, layout):
 
 kern_t, traffic_t, stats_t = layout_summary("", "tiled")
 kern_r, traffic_r, stats_r = layout_summary("_rm", "rowmajor")
-json.dump(traffic_t, open(os.path.join(P, "traffic_%s_tiled.json" % tag), "w"), indent=1)
-json.dump(traffic_r, open(os.path.join(P, "traffic_%s.json" % tag), "w"), indent=1)
+json.dump(traffic_t, open(os.path.join(P, "traffic_%s_cold_tiled.json" % tag), "w"), indent=1)
+json.dump(traffic_r, open(os.path.join(P, "traffic_%s_cold_rowmajor.json" % tag), "w"), indent=1)
 csv.writer(open(os.path.join(P, "%s_kernel_stats.csv" % tag), "w")).writerows(stats_t)
 csv.writer(open(os.path.join(P, "%s_kernel_stats_rowmajor.csv" % tag), "w")).writerows(stats_r)
 
@@ -93,23 +94,26 @@ lowmem["Mpix_edges_per_s"] = {n: round(16 * 60 * 80 / t, 1) for n, t in lowmem["
 lowmem["Mpix_edges_per_s_one_launch"] = {n: round(16 * 60 * 80 / t, 1) for n, t in lowmem["all_levels_in_one_launch_us"].items()}
 json.dump(lowmem, open(os.path.join(P, "%s_lowmem_kernels.json" % tag), "w"), indent=1)
 
-b = json.load(open(os.path.join(G, "bench.json")))
-br = json.load(open(os.path.join(G, "bench_rowmajor.json")))
-bp = json.load(open(os.path.join(G, "bench_probe.json")))
-bl = json.load(open(os.path.join(G, "bench_lowmem.json")))
-cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))]
-bh = json.load(open(os.path.join(G, "bench_nhwc_f16.json"))) if os.path.exists(os.path.join(G, "bench_nhwc_f16.json")) else None
+def load(name):
+    f = os.path.join(G, name)
+    return json.load(open(f)) if os.path.exists(f) and os.path.getsize(f) > 0 else None
+
+
+b = load("bench.json")
+bl = load("bench_lowmem.json")
+bb = load("bench_backend.json")
+cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))] if os.path.exists(os.path.join(G, "compare_ref.jsonl")) else None
 import shutil
 for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_calls.json", "%s_e2e_glue_calls.json"),
-                 ("prof_init.txt", "%s_corrblock_init.txt")):
+                 ("prof_init.txt", "%s_corrblock_init.txt"), ("ab_final.jsonl", "%s_ab_metric_kernel_variants.jsonl"),
+                 ("pmc_cold.txt", "%s_pmc_metric_kernel_cold.txt"), ("ab_lowmem.jsonl", "%s_ab_lowmem_levels.jsonl")):
     if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 0:
         shutil.copy(os.path.join(G, src), os.path.join(P, dst % tag))
-keep = ("value", "ms_per_step", "roofline", "config")
-json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py (tiled pyramid), bench.py --layout rowmajor, "
-                   "bench.py --probe, rocprofv3 kernel-trace stats, PMC traffic for both layouts, low-memory kernel trace, "
-                   "comparison with the reference kernels (oracle/_ref) on the same device",
-           "bench": b, "bench_rowmajor": {k: br[k] for k in keep}, "bench_probe": {k: bp[k] for k in keep}, "bench_lowmem_config4": bl,
-           "bench_out_format_nhwc_f16": {k: bh[k] for k in keep} if bh else None,
+json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py line (cold-cache headline + extra: probe on, row-major "
+                   "operator path, warm cache, config 3, config 4), bench.py --workload lowmem / backend, rocprofv3 kernel-trace stats "
+                   "and PMC traffic of the metric kernel in cold mode for both pyramid layouts, low-memory kernel trace, comparison "
+                   "with the reference kernels (oracle/_ref) on the same device",
+           "bench": b, "bench_lowmem_config4": bl, "bench_backend_config5_n1": bb,
            "kernel_stats_defcorr_tiled": dict(kern_t), "kernel_stats_defcorr_rowmajor": dict(kern_r),
            "traffic_tiled": traffic_t, "traffic_rowmajor": traffic_r, "lowmem_kernels": lowmem, "compare_ref": cmp_},
           open(os.path.join(P, "%s_final.json" % tag), "w"), indent=1)

@@ -19,7 +19,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_b_*/")):
     if not fs: continue
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(fs[0])):
-        if "defcorr_gather" not in r["Kernel_Name"]: continue
+        if "defcorr_" not in r["Kernel_Name"]: continue
         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for c, v in acc.items():
         print(c, "%.5g" % (sum(v) / len(v)), "(%d launches)" % len(v))
