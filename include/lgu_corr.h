@@ -293,6 +293,19 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
                                int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
                                int radius, const long long* ii, const long long* jj, void* stream);
 
+/* The same with every fmap2[l] in this library's CHUNK-PLANAR form (F, C/k, H2l, W2l, k), k = 8 halves / 4 floats (16
+ * bytes of channels); fmap1 stays channel-last.  Same results bit for bit (same products, same summation order); the
+ * sweep's operand loads then read 256 contiguous bytes per 16 x-adjacent positions instead of 16 separate lines, which
+ * is what bounds it.  AltCorrBlock keeps its feature pyramid in this form. */
+int lgu_lowmem_pyramid_chunked_fwd_h16(const void* fmap1_half, const void* const* fmap2_half, const float* coords,
+                                       float* const* offsets, float* out,
+                                       int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                                       int radius, const long long* ii, const long long* jj, void* stream);
+int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords,
+                                       float* const* offsets, float* out,
+                                       int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                                       int radius, const long long* ii, const long long* jj, void* stream);
+
 /* ---- dense bundle adjustment: device kernels (first version) ---------------------------
  * The data-parallel kernels of droid_backends.ba (reference src/droid.cpp:88-107 -> src/droid_kernels.cu:1314-1434).
  * The reference's host driver copies every block to the CPU and solves with Eigen; here lgu-slam_amd/ba.py assembles

@@ -72,17 +72,22 @@ template <> struct MmT<float> {
   }
 };
 
-// Fallback for boxes larger than the patch: the four corner dots of one tap straight from memory.
+// Fallback for boxes larger than the patch: the four corner dots of one tap straight from memory.  F2 is addressed
+// as position * pstride + chunk * cstride (+ element in chunk): channel-last maps have pstride = C, cstride = EPL; the
+// chunk-planar form (MmParams::f2_chunked) has pstride = EPL, cstride = H2 * W2 * EPL.
 template <typename T>
-__device__ __noinline__ float4 corner_dots(const T* f1p, const T* p11, int C, int W2, int mask) {
+__device__ __noinline__ float4 corner_dots(const T* f1p, const T* F2, ptrdiff_t pos11, int C, int W2, int mask,
+                                           ptrdiff_t pstride, ptrdiff_t cstride) {
   typedef typename MmT<T>::frag frag;
+  constexpr int EPL = MmT<T>::EPL;
   float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-  for (int c = 0; c < C; c += MmT<T>::EPL) {
+  for (int c = 0; c < C; c += EPL) {
     const frag f = *reinterpret_cast<const frag*>(f1p + c);
-    if (mask & 1) q11 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + c), q11);
-    if (mask & 2) q21 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + C + c), q21);
-    if (mask & 4) q12 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + (size_t)W2 * C + c), q12);
-    if (mask & 8) q22 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(p11 + (size_t)W2 * C + C + c), q22);
+    const T* base = F2 + (ptrdiff_t)(c / EPL) * cstride;
+    if (mask & 1) q11 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(base + pos11 * pstride), q11);
+    if (mask & 2) q21 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(base + (pos11 + 1) * pstride), q21);
+    if (mask & 4) q12 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(base + (pos11 + W2) * pstride), q12);
+    if (mask & 8) q22 = MmT<T>::dot(f, *reinterpret_cast<const frag*>(base + (pos11 + W2 + 1) * pstride), q22);
   }
   return make_float4(q11, q21, q12, q22);
 }
@@ -129,6 +134,12 @@ struct MmParams {
   int H2[MM_MAXL], W2[MM_MAXL];
   int L, B, S, H1, W1, blocks_x, blocks_y, xcd_map, vec_out;
   int lbase;             // pyramid level of fmap2[0]: level l of the launch samples at coords / 2^(lbase + l)
+  // fmap2 storage.  0: channel-last (F,H2,W2,C), the operators' layout.  1: chunk-planar (F, C/EPL, H2, W2, EPL) with
+  // EPL = 16 bytes of channels: the 16 x-adjacent positions an MFMA B fragment covers are then 256 CONTIGUOUS bytes per
+  // 16-byte channel chunk, where channel-last puts them 2C bytes apart.  The vector L1 serves a load quad by quad
+  // (4 lanes), one access per distinct 128-byte line in the quad: 64 accesses per fragment load channel-last, 16-20
+  // chunk-planar — the access rate, not L2 bandwidth, is what bounds the sweep (AltCorrBlock keeps its pyramid in this form).
+  int f2_chunked;
   const long long* ii;   // optional frame indices (device, int64): edge b reads fmap1[ii[b]] and fmap2[l][jj[b]]
   const long long* jj;   // straight from the frame buffers — no gathered per-edge copies; null = fmap*[b]
 };
@@ -306,10 +317,12 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
       }
     const int ngx = (UX1 - UX0 + MM_BOX) >> 4;  // groups of 16 positions per window row
     const int nit = ngx * (UY1 - UY0 + 1);
+    // k-step s of lane (lg, lx) holds channels CPS s + EPL lg .. + EPL - 1 of position gx0 + lx
+    const size_t bstep = p.f2_chunked ? (size_t)4 * H2 * W2 * EPL : (size_t)CPS;  // elements from k-step s to s + 1
     auto bptr = [&](int y, int gx0) {
       int x = gx0 + lx;
       x = x < W2 ? x : W2 - 1;  // padded positions re-read the last column; their results land in no box
-      return F2 + ((size_t)(y * W2 + x)) * C + EPL * lg;
+      return p.f2_chunked ? F2 + (((size_t)lg * H2 + y) * W2 + x) * EPL : F2 + ((size_t)(y * W2 + x)) * C + EPL * lg;
     };
     // MM_PF groups in flight: slot j holds iteration it + j; it is refilled for it + j + MM_PF right after use.
     // (The sweep is bound by the L2 -> CU read rate, ~70 GB/s per CU; a hand-counted s_waitcnt variant with
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
       if (j < nit) {
         const T* p = bptr(yl, gxl);
 #pragma unroll
-        for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + CPS * s);
+        for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + bstep * s);
         gxl += 16;
         if (gxl > UX1) { gxl = UX0; yl++; }
       }
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
           if (it + j + MM_PF < nit) {
             const T* p = bptr(yl, gxl);
 #pragma unroll
-            for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + CPS * s);
+            for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + bstep * s);
             gxl += 16;
             if (gxl > UX1) { gxl = UX0; yl++; }
           }
@@ -403,8 +416,9 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
           if (b12) q12 = D[MM_BOX];
           if (b22) q22 = D[MM_BOX + 1];
         } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
-          const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2 + ((ptrdiff_t)h2 * W2 + w2) * C, C, W2,
-                                          (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0));
+          const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
+                                          (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0),
+                                          p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
           q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
         }
         res[m][q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
@@ -516,7 +530,7 @@ extern "C" {
 
 static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
                          float* out, int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                         int radius, const long long* ii, const long long* jj, void* stream) {
+                         int radius, const long long* ii, const long long* jj, void* stream, bool chunked = false) {
   using namespace lgu;
   if (!fmap1 || !fmap2 || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
   if (L < 1 || L > MM_MAXL || lbase < 0 || lbase > 16 || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0)
@@ -533,6 +547,7 @@ static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2,
   p.coords = coords; p.corr = out;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.ii = ii; p.jj = jj;
+  p.f2_chunked = chunked ? 1 : 0;
   if (B == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int rc = half ? mfma_dispatch<_Float16>(p, C, radius, st) : mfma_dispatch<float>(p, C, radius, st);
@@ -550,6 +565,21 @@ int lgu_lowmem_pyramid_fwd_f32(const float* fmap1, const float* const* fmap2, co
                                int NO, int radius, const long long* ii, const long long* jj, void* stream) {
   return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, lbase, B, S, H1, W1,
                        H2, W2, C, NO, radius, ii, jj, stream);
+}
+
+int lgu_lowmem_pyramid_chunked_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords,
+                                       float* const* offsets, float* out, int L, int lbase, int B, int S, int H1, int W1,
+                                       const int* H2, const int* W2, int C, int NO, int radius, const long long* ii,
+                                       const long long* jj, void* stream) {
+  return pyramid_entry(true, fmap1, fmap2, coords, offsets, out, L, lbase, B, S, H1, W1, H2, W2, C, NO, radius, ii, jj, stream, true);
+}
+
+int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* fmap2, const float* coords,
+                                       float* const* offsets, float* out, int L, int lbase, int B, int S, int H1, int W1,
+                                       const int* H2, const int* W2, int C, int NO, int radius, const long long* ii,
+                                       const long long* jj, void* stream) {
+  return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, lbase, B, S, H1, W1,
+                       H2, W2, C, NO, radius, ii, jj, stream, true);
 }
 
 }  // extern "C"

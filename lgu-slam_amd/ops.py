@@ -288,7 +288,9 @@ class LowmemPyramidPlan:
     The pointer tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first
     call) for channel counts / radii the matrix-core kernel does not serve."""
 
-    def __init__(self, fmap1, fmap2s, offsets, radius, ii=None, jj=None, lbase=0):
+    def __init__(self, fmap1, fmap2s, offsets, radius, ii=None, jj=None, lbase=0, chunked=False):
+        """chunked=True: every fmap2s[l] is in the chunk-planar form of lowmem_chunked() — (F, C/k, H2l, W2l, k) — instead
+        of channel-last (F, H2l, W2l, C); same results bit for bit, the sweep's loads become line-friendly."""
         L = len(fmap2s)
         if len(offsets) != L or not 1 <= L <= 4:
             raise RuntimeError("LowmemPyramidPlan: need 1..4 levels and one offset entry (tensor or None) per level")
@@ -312,11 +314,20 @@ class LowmemPyramidPlan:
         self.NO = max([o.shape[0] for o in offsets if o is not None] or [max(self.B, 1)])
         self._f2 = (_vp * L)(*[f.data_ptr() for f in fmap2s])
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
-        self._h2 = (ctypes.c_int * L)(*[f.shape[1] for f in fmap2s])
-        self._w2 = (ctypes.c_int * L)(*[f.shape[2] for f in fmap2s])
+        if chunked:
+            k = 8 if dt == torch.float16 else 4
+            for f in fmap2s:
+                if f.dim() != 5 or f.shape[4] != k or f.shape[1] * k != self.C:
+                    raise RuntimeError("chunked fmap2 levels must be (F, C/%d, H2, W2, %d)" % (k, k))
+        self._h2 = (ctypes.c_int * L)(*[f.shape[2 if chunked else 1] for f in fmap2s])
+        self._w2 = (ctypes.c_int * L)(*[f.shape[3 if chunked else 2] for f in fmap2s])
         self._ii = ii.data_ptr() if ii is not None and self.B else None
         self._jj = jj.data_ptr() if jj is not None and self.B else None
-        self._fn = _lib.load().lgu_lowmem_pyramid_fwd_h16 if dt == torch.float16 else _lib.load().lgu_lowmem_pyramid_fwd_f32
+        lib = _lib.load()
+        if chunked:
+            self._fn = lib.lgu_lowmem_pyramid_chunked_fwd_h16 if dt == torch.float16 else lib.lgu_lowmem_pyramid_chunked_fwd_f32
+        else:
+            self._fn = lib.lgu_lowmem_pyramid_fwd_h16 if dt == torch.float16 else lib.lgu_lowmem_pyramid_fwd_f32
 
     def __call__(self, coords, out=None):
         _check(coords, "coords")
@@ -335,10 +346,20 @@ class LowmemPyramidPlan:
         return out
 
 
-def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None, ii=None, jj=None, lbase=0):
+def lowmem_chunked(fmap):
+    """Channel-last feature map (F,H,W,C), half or float -> the chunk-planar form (F, C/k, H, W, k), k = 16 bytes of
+    channels (8 halves / 4 floats), that LowmemPyramidPlan(chunked=True) reads.  A permuted copy (setup, once per map)."""
+    k = 8 if fmap.dtype == torch.float16 else 4
+    F, H, W, C = fmap.shape
+    if C % k != 0:
+        raise RuntimeError("lowmem_chunked: C must be a multiple of %d" % k)
+    return fmap.view(F, H, W, C // k, k).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None, ii=None, jj=None, lbase=0, chunked=False):
     """One-shot form of LowmemPyramidPlan (half or float feature maps)."""
     with torch.cuda.device(fmap1.device):
-        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius, ii=ii, jj=jj, lbase=lbase)(coords, out=out)
+        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius, ii=ii, jj=jj, lbase=lbase, chunked=chunked)(coords, out=out)
 
 
 PYR_PROBE, PYR_TILED, PYR_COORDS_LAST = 1, 2, 4  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)

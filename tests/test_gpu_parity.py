@@ -1340,6 +1340,39 @@ def test_lowmem_pyramid_reads_frame_buffers_in_place(lgu, half):
         lgu.ops.LowmemPyramidPlan(frames[0], frames, oa, 3, ii=ii)
 
 
+@pytest.mark.parametrize("half", [True, False])
+@pytest.mark.parametrize("big_offsets", [False, True])
+def test_lowmem_chunk_planar_feature_maps_are_bitwise_the_channel_last_ones(lgu, half, big_offsets):
+    """LowmemPyramidPlan(chunked=True): fmap2 levels stored (F, C/k, H, W, k) (ops.lowmem_chunked) give the channel-last
+    launch's output BIT FOR BIT — same products, same summation order, other addresses — with frame indices and with
+    per-edge maps, ragged level sizes, and offsets beyond +-4 (boxes larger than a patch take the per-tap fallback,
+    which reads the chunk-planar form too)."""
+    torch.manual_seed(33)
+    F_, H, W, C, L = 4, 22, 30, 128 if half else 64, 3
+    cast = (lambda t: t.half()) if half else (lambda t: t)
+    frames = [cast(torch.randn(F_, max(H >> l, 1), max(W >> l, 1), C, device="cuda") * 0.125) for l in range(L)]
+    chunked = [lgu.ops.lowmem_chunked(f) for f in frames]
+    k = 8 if half else 4
+    assert tuple(chunked[1].shape) == (F_, C // k, H >> 1, W >> 1, k)
+    assert torch.equal(chunked[1][2, 3, 5, 7], frames[1][2, 5, 7, 3 * k:4 * k])
+    ii = torch.tensor([0, 1, 3, 2, 2, 0], device="cuda")
+    jj = torch.tensor([1, 2, 0, 3, 0, 3], device="cuda")
+    E = ii.numel()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(E, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = ((9.0 if big_offsets else 4.0) * torch.tanh(torch.randn(E, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    oa, ob = [o0.clone(), None, None], [o0.clone(), None, None]
+    want = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], frames, coords, oa, 3, ii=ii, jj=jj)
+    got = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], chunked, coords, ob, 3, ii=ii, jj=jj, chunked=True)
+    assert torch.equal(got, want) and torch.equal(oa[0], ob[0])
+    # per-edge maps (no frame indices), radius 1 probe form
+    pe = lgu.ops.lowmem_pyramid_forward_mixed(frames[0][ii].contiguous(), [lgu.ops.lowmem_chunked(frames[1][jj].contiguous())], coords,
+                                              [None], 1, lbase=1, chunked=True)
+    assert torch.equal(pe, lgu.ops.lowmem_pyramid_forward_mixed(frames[0], [frames[1]], coords, [None], 1, ii=ii, jj=jj, lbase=1))
+    with pytest.raises(RuntimeError, match="chunked fmap2"):
+        lgu.ops.LowmemPyramidPlan(frames[0], frames, [None] * L, 3, ii=ii, jj=jj, chunked=True)
+
+
 def test_corrblock_slot_store_cat_and_getitem_move_no_volume(lgu):
     """The inference CorrBlock keeps its pyramid in slot-indirected buffers: `cat` copies only the new edges,
     `__getitem__` (bool mask, as factor_graph.rm_factors uses, or an index tensor) only edits the slot list, freed
