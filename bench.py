@@ -292,7 +292,8 @@ def lowmem_setup(ops, dev, B, seed):
     coords = (torch.stack([xs, ys], -1)[None, None] + 3.0 * randn(B, 1, H1, W1, 2)).contiguous()
     o0 = (4 * torch.tanh(randn(B, H1, W1, 7, 7, 2))).contiguous()
     o1 = ((4 * torch.tanh(randn(B, H1, W1, 7, 7, 2)) + o0) / 2).contiguous()
-    plan = ops.LowmemPyramidPlan(f1, f2s, [o0, o1, None, None], R)
+    # the target maps in the chunk-planar form AltCorrBlock keeps them in (ops.lowmem_chunked; conversion is setup)
+    plan = ops.LowmemPyramidPlan(f1, [ops.lowmem_chunked(f) for f in f2s], [o0, o1, None, None], R, chunked=True)
     out = torch.empty(B, 1, L * 49, H1, W1, device=dev)
     return dict(B=B, H1=H1, W1=W1, C=C, L=L, R=R, f1=f1, f2s=f2s, coords=coords, o0=o0, o1=o1, plan=plan, out=out,
                 units=B * H1 * W1)
@@ -372,7 +373,8 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
                "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16 features, f32 accumulate", "data": "synthetic",
                "config": {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, one chunk of "
-                                      "%d edges per GPU, all levels in one launch" % S["B"],
+                                      "%d edges per GPU, all levels in one call (levels with offsets + zero-offset levels: 2 launches), "
+                                      "target maps chunk-planar as AltCorrBlock stores them" % S["B"],
                           "edges_per_gpu": S["B"], "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)"},
                "roofline": roof,
                "cpu_baseline": None if (args.no_cpu or world > 1) else lowmem_cpu_baseline(S)}

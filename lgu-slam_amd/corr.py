@@ -481,9 +481,14 @@ class AltCorrBlock:
                 frames = [p_[0].contiguous() for p_ in self.pyramid]            # (N,Hl,Wl,C): views of the stored pyramid
                 if not mixed:
                     frames = [f.float() for f in frames]
+                # the matrix-core sweep reads the target maps in the chunk-planar form (ops.lowmem_chunked: 16 x-adjacent
+                # positions of a 16-byte channel chunk are contiguous): made once per block, like the pyramid itself
+                if getattr(self, "_chunked", None) is None or self._chunked[0].dtype != frames[0].dtype:
+                    self._chunked = [ops.lowmem_chunked(f) for f in frames]
                 iic, jjc = ii.contiguous(), jj.contiguous()
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
-                probe = ops.lowmem_pyramid_forward_mixed(frames[0], [frames[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1)
+                probe = ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1,
+                                                         chunked=True)
                 o1 = self.offset[1]
                 if o1.dtype == torch.float32 and o1.is_contiguous() and not o1.requires_grad:
                     ops.probe_mask_scale_(probe, o1)   # variance, sigmoid and the scaling in one pass, in place
@@ -493,7 +498,7 @@ class AltCorrBlock:
                     self.offset[1] = self.offset[1] * mask
                 offs = [None if zero_level[i] else self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
                         for i in range(self.num_levels)]
-                fused = ops.lowmem_pyramid_forward_mixed(frames[0], frames, c0, offs, self.radius, ii=iic, jj=jjc)
+                fused = ops.lowmem_pyramid_forward_mixed(frames[0], self._chunked, c0, offs, self.radius, ii=iic, jj=jjc, chunked=True)
                 return fused.view(B, N, -1, H, W).unsqueeze(-1)   # (1,E,L*rd*rd,H,W,S=1)
             except _lib.UnsupportedShape:
                 # channel counts / radii the matrix-core kernel does not serve: per-level operators below

@@ -37,7 +37,14 @@ constexpr int MM_BOX = 16;           // patch row pitch / largest box side
 constexpr int MM_PP = MM_BOX * MM_BOX + 4;  // patch pitch per pixel: the 4 pixel groups of one scatter land on different bank quarters
 constexpr int MM_MAXMT = 2;          // 4 x 4 pixel sub-blocks (MFMA row tiles) one wave can own
 __host__ __device__ constexpr int mm_outp(int MT) { return 16 * MT + 4; }  // output transpose pitch (pixels + pad, 16-byte aligned rows)
-__host__ __device__ constexpr int mm_lds_floats(int MT) { return MT * (MM_BP * MM_PP + MM_BP * 4); }
+// Zero-offset levels (ZO kernels): every tap box is the (2R+2)^2 <= 8 x 8 integer lattice around the level coords, so a
+// patch is 8 x 8 (+ 4 pad): 4.6 KB per 16 pixels instead of 16.9 KB, and no offset is loaded or held.
+constexpr int MM_GUARD = 20;         // floats in front of the patches (>= MM_BOX + 1): see the sampling phase
+constexpr int MM_ZBOX = 8;
+constexpr int MM_ZPP = MM_ZBOX * MM_ZBOX + 4;
+__host__ __device__ constexpr int mm_lds_floats(int MT, bool ZO = false) {
+  return MM_GUARD + MT * (MM_BP * (ZO ? MM_ZPP : MM_PP) + MM_BP * 4);
+}
 
 // Element-type traits.  One k-step covers CPS channels; lane (lg, lx) holds EPL consecutive channels starting at
 // EPL * lg of row/column lx.  half: one v_mfma_f32_16x16x32_f16 per step.  float: four v_mfma_f32_16x16x4_f32 per
@@ -134,6 +141,8 @@ struct MmParams {
   int H2[MM_MAXL], W2[MM_MAXL];
   int L, B, S, H1, W1, blocks_x, blocks_y, xcd_map, vec_out;
   int lbase;             // pyramid level of fmap2[0]: level l of the launch samples at coords / 2^(lbase + l)
+  int lvl0, Ltot;        // output: level l of this launch writes channels (lvl0 + l) * NT .. of Ltot * NT (a pyramid call may be
+                         // split into a launch for the levels with offsets and one for the zero-offset levels)
   // fmap2 storage.  0: channel-last (F,H2,W2,C), the operators' layout.  1: chunk-planar (F, C/EPL, H2, W2, EPL) with
   // EPL = 16 bytes of channels: the 16 x-adjacent positions an MFMA B fragment covers are then 256 CONTIGUOUS bytes per
   // 16-byte channel chunk, where channel-last puts them 2C bytes apart.  The vector L1 serves a load quad by quad
@@ -153,20 +162,28 @@ struct MmParams {
 // Lane layout outside the sweep: row = lane / 16 is a pixel of the current pass (pass (m, q) serves row q of sub-block
 // m: pixel column 4 m + row), j = lane % 16 carries the taps j, j + 16, j + 32, j + 48 of that pixel, so tap boxes
 // reduce inside 16-lane rows with DPP only.
-template <int R, int KS, typename T, int MT>
-__global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(const MmParams p) {
+// ZO: a launch whose levels all have structurally zero offsets (levels >= 2 of AltCorrBlock, corr.py:232-235; the r = 1
+// probe; altcorr_forward).  All taps of a pixel then share one fractional part and its box is the lattice — known from
+// the coords alone: no offset loads, no per-tap box reduction, 8 x 8 patches.  The small LDS and register footprint
+// (no offsets held across the sweep) doubles the resident waves, which is what these overhead-bound levels need
+// (their sweep is 2-3 us of an 11 us wave life: tools/diag/run_mm_stamps.py).
+template <int R, int KS, typename T, int MT, bool ZO>
+__global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma_kernel(const MmParams p) {
   typedef typename MmT<T>::frag frag;
   constexpr int CPS = MmT<T>::CPS, EPL = MmT<T>::EPL;
   constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
   constexpr int TI = (NT + 15) / 16;   // tap slots per lane
   constexpr int CEN = R * RD + R;      // centre tap
-  constexpr int MM_PF = KS <= 4 ? 4 : 2;  // position groups in flight (16 bytes x KS per lane each)
+  constexpr int MM_PF = (KS <= 4 && !ZO) ? 4 : 2;  // position groups in flight (16 bytes x KS per lane each)
+  constexpr int BOXP = ZO ? MM_ZBOX : MM_BOX;      // patch row pitch
+  constexpr int PP = ZO ? MM_ZPP : MM_PP;          // patch pitch per pixel
+  static_assert(!ZO || 2 * R + 2 <= MM_ZBOX, "zero-offset lattice must fit the small patch");
   static_assert(sizeof(frag) == 16, "one 16-byte load per lane and k-step");
   constexpr int NP = MM_BP * MT;        // pixels of the block
   constexpr int MM_OUTP = mm_outp(MT);
   extern __shared__ float smem[];
-  float* const patch = smem;                                          // [NP][MM_PP]
-  int* const pbox = reinterpret_cast<int*>(smem + NP * MM_PP);        // [NP][xlo,ylo,bw,bh]
+  float* const patch = smem + MM_GUARD;                               // [NP][PP]
+  int* const pbox = reinterpret_cast<int*>(patch + NP * PP);          // [NP][xlo,ylo,bw,bh]
   const int lane = threadIdx.x;
   const int lx = lane & 15, lg = lane >> 4;
   const int B = p.B, S = p.S, H1 = p.H1, W1 = p.W1, blocks_x = p.blocks_x;
@@ -201,20 +218,10 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
   const T* const F1 = static_cast<const T*>(p.fmap1) + f1i * HW1 * C;
   const T* const F2 = fmap2 + f2i * H2 * W2 * C;
   // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets (altcorr)
-  float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+  float* const obase = (!ZO && offset) ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
   const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
 
   MM_STAMP(0);
-  // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested first, consumed by the sweep
-  frag a[MT][KS];
-#pragma unroll
-  for (int m = 0; m < MT; m++) {
-    int h1 = by * 4 + (lx >> 2), w1 = (bx * MT + m) * 4 + (lx & 3);
-    h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
-    const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
-#pragma unroll
-    for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
-  }
   // ---- phase 0: sample positions and tap boxes (4 pixels per pass, one per lane row) ----
   int tix[TI], tiy[TI];         // offset / output index [ix][iy] of this lane's tap slots
 #pragma unroll
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
     tix[i] = t / RD;
     tiy[i] = t - tix[i] * RD;
   }
-  float2 cvv[MT][4], o0[MT][4][TI];
+  float2 cvv[MT][4], o0[MT][4][ZO ? 1 : TI];   // ZO: no offsets (the one dummy entry is never read)
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -233,14 +240,27 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
       const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
       cvv[m][q] = cbase[pix];
       cvv[m][q].x *= cscale; cvv[m][q].y *= cscale;
+      if constexpr (!ZO) {
 #pragma unroll
-      for (int i = 0; i < TI; i++) {
-        const int t = lx + 16 * i;
-        o0[m][q][i] = make_float2(0.f, 0.f);
-        if (obase && pv && t < NT) o0[m][q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
+        for (int i = 0; i < TI; i++) {
+          const int t = lx + 16 * i;
+          o0[m][q][i] = make_float2(0.f, 0.f);
+          if (obase && pv && t < NT) o0[m][q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
+        }
       }
     }
-  if (obase) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
+  // A fragments: lane (lg, lx) holds channels 32 s + 8 lg .. + 7 of pixel lx; requested right behind the
+  // coords / offsets (loads return in order: the box computation must not wait for these 4 KB), consumed by the sweep
+  frag a[MT][KS];
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    int h1 = by * 4 + (lx >> 2), w1 = (bx * MT + m) * 4 + (lx & 3);
+    h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
+    const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
+#pragma unroll
+    for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
+  }
+  if constexpr (!ZO) if (obase) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -263,21 +283,30 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
       const int h1 = by * 4 + q, w1r = (bx * MT + m) * 4 + lg;
       const bool pv = h1 < H1 && w1r < W1;
       int lo = 0x7fff7fff, hi = (int)0x80008000;
+      if constexpr (ZO) {
+        // taps i, j = -R..R at floor(c) + (i, j), corners one further: the lattice [f - R, f + R + 1]^2 clipped to the map
+        // (= what the per-tap reduction below yields for zero offsets; the x and y ranges clip independently)
+        const int fx = (int)floorf(cvv[m][q].x), fy = (int)floorf(cvv[m][q].y);
+        const int xa = fx - R > 0 ? fx - R : 0, xb = fx + R + 1 < W2 ? fx + R + 1 : W2 - 1;
+        const int ya = fy - R > 0 ? fy - R : 0, yb = fy + R + 1 < H2 ? fy + R + 1 : H2 - 1;
+        if (pv && xa <= xb && ya <= yb) { lo = pk16(xa, ya); hi = pk16(xb, yb); }
+      } else {
 #pragma unroll
-      for (int i = 0; i < TI; i++) {
-        const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;  // :82-83
-        const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
-        const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
-        const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
-        const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
-        lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
-        hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+        for (int i = 0; i < TI; i++) {
+          const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;  // :82-83
+          const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
+          const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
+          const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
+          const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
+          lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
+          hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+        }
+        lo = row_pk_reduce<true>(lo);
+        hi = row_pk_reduce<false>(hi);
       }
-      lo = row_pk_reduce<true>(lo);
-      hi = row_pk_reduce<false>(hi);
       const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
       const bool any = xhi >= xlo && yhi >= ylo;
-      const bool boxed = any && xhi - xlo < MM_BOX && yhi - ylo < MM_BOX;
+      const bool boxed = any && xhi - xlo < BOXP && yhi - ylo < BOXP;
       ulo = boxed ? pk_min(ulo, lo) : ulo;
       uhi = boxed ? pk_max(uhi, hi) : uhi;
       blo[m][q] = lo;
@@ -313,9 +342,9 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
         const int xlo = pbox[p * 4 + 0], ylo = pbox[p * 4 + 1];
         sbw[m][r] = pbox[p * 4 + 2]; sbh[m][r] = pbox[p * 4 + 3];
         sxv[m][r] = lx - xlo; sylo[m][r] = ylo;
-        sbase[m][r] = p * MM_PP - ylo * MM_BOX - xlo + lx;
+        sbase[m][r] = p * PP - ylo * BOXP - xlo + lx;
       }
-    const int ngx = (UX1 - UX0 + MM_BOX) >> 4;  // groups of 16 positions per window row
+    const int ngx = (UX1 - UX0 + 16) >> 4;  // groups of 16 positions per window row
     const int nit = ngx * (UY1 - UY0 + 1);
     // k-step s of lane (lg, lx) holds channels CPS s + EPL lg .. + EPL - 1 of position gx0 + lx
     const size_t bstep = p.f2_chunked ? (size_t)4 * H2 * W2 * EPL : (size_t)CPS;  // elements from k-step s to s + 1
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
             gxl += 16;
             if (gxl > UX1) { gxl = UX0; yl++; }
           }
-          const int yg = y * MM_BOX + gx0;
+          const int yg = y * BOXP + gx0;
 #pragma unroll
           for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -398,11 +427,12 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
       const bool pv = h1 < H1 && w1r < W1;
       const int xlo = pk_lo(blo[m][q]), ylo = pk_hi(blo[m][q]);
       const bool has_patch = (bwh[m][q] & 0xff) != 0, fallback = (bwh[m][q] >> 16) != 0;
-      const float* const Dp = patch + (m * MM_BP + q * 4 + lg) * MM_PP;
+      const float* const Dp = patch + (m * MM_BP + q * 4 + lg) * PP;
 #pragma unroll
       for (int i = 0; i < TI; i++) {
         const bool tv = pv && lx + 16 * i < NT;
-        const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;
+        const float xs = ZO ? cvv[m][q].x : cvv[m][q].x + o0[m][q][ZO ? 0 : i].x;
+        const float ys = ZO ? cvv[m][q].y : cvv[m][q].y + o0[m][q][ZO ? 0 : i].y;
         const float fxs = floorf(xs), fys = floorf(ys);
         const float dx = xs - fxs, dy = ys - fys;  // :87-88
         const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
@@ -410,11 +440,17 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
         const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
         float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
         if (tv && has_patch) {
-          const float* D = Dp + (h2 - ylo) * MM_BOX + (w2 - xlo);
-          if (b11) q11 = D[0];
-          if (b21) q21 = D[1];
-          if (b12) q12 = D[MM_BOX];
-          if (b22) q22 = D[MM_BOX + 1];
+          // the four corners are read unconditionally (two 8-byte LDS reads) and the per-corner zero padding is a
+          // select: an in-bounds corner always lies inside the pixel's box, so its entry is where the index says; the
+          // others read whatever is there (inside the LDS allocation: MM_GUARD floats in front of the patches cover a
+          // top-left one row / column before the box, the box table behind them covers the bottom-right overshoot)
+          const int idx = (b11 || b21 || b12 || b22) ? (h2 - ylo) * BOXP + (w2 - xlo) : 0;
+          const float* D = Dp + idx;
+          const float d0 = D[0], d1 = D[1], d2 = D[BOXP], d3 = D[BOXP + 1];
+          q11 = b11 ? d0 : 0.f;
+          q21 = b21 ? d1 : 0.f;
+          q12 = b12 ? d2 : 0.f;
+          q22 = b22 ? d3 : 0.f;
         } else if (tv && fallback) {  // box larger than 16 x 16: this tap's four corner dots, channels in order
           const float4 qq = corner_dots<T>(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
                                           (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0),
@@ -441,7 +477,7 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float* const cb = p.corr + (((size_t)b * S + n) * p.L + lvl) * NT * HW1;
+  float* const cb = p.corr + (((size_t)b * S + n) * p.Ltot + p.lvl0 + lvl) * NT * HW1;
   for (int idx = lane; idx < NT * 4 * MT; idx += kWave) {
     const int t = idx / (4 * MT), qm = idx - t * (4 * MT);
     const int q = qm / MT, m = qm - q * MT;
@@ -461,10 +497,10 @@ __global__ __launch_bounds__(kWave, MT == 1 ? 2 : 1) void lowmem_mfma_kernel(con
   MM_STAMP(5);
 }
 
-template <int R, int KS, typename T, int MT>
+template <int R, int KS, typename T, int MT, bool ZO>
 static int launch_mfma_mt(MmParams p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)mm_lds_floats(MT);
-  auto kern = lowmem_mfma_kernel<R, KS, T, MT>;
+  const size_t lds = sizeof(float) * (size_t)mm_lds_floats(MT, ZO);
+  auto kern = lowmem_mfma_kernel<R, KS, T, MT, ZO>;
   p.blocks_x = (p.W1 + 4 * MT - 1) / (4 * MT);
   p.blocks_y = (p.H1 + 3) / 4;
   const int blocks = p.blocks_x * p.blocks_y;
@@ -476,15 +512,40 @@ static int launch_mfma_mt(MmParams p, hipStream_t st) {
   return launch_status();
 }
 
+// One pyramid call = one launch per run of levels of equal kind (offsets / structurally zero offsets): AltCorrBlock's
+// [off, off, null, null] is two launches, the second with the ZO kernel.
 // LGU_LOWMEM_MT (debug / A-B only): pixel sub-blocks per wave, 1 (default) or 2.  Measured (tools/ab_lowmem.py,
 // profiles/r02_ab_lowmem_mt.jsonl, config 4 shapes): MT = 2 moves 1.7x fewer bytes from L2 and wins only at level 0
 // (108 vs 116 us); at 4 waves per CU the latency of the box and sampling phases is exposed and the coarse levels lose
-// (51 vs 37 us, 49 vs 32 us): 229 vs 220 us for the four levels in one launch.  The sweep's L2 traffic is therefore
-// not what bounds this kernel at 8-9 waves per CU; occupancy (LDS: 16.6 KB of patches per 16 pixels) is.
+// (51 vs 37 us, 49 vs 32 us): 229 vs 220 us for the four levels in one launch.
+// LGU_LOWMEM_ZO (debug / A-B only): 0 = zero-offset levels through the general kernel too.
 template <int R, int KS, typename T>
 static int launch_mfma(const MmParams& p, hipStream_t st) {
-  if (env_int("LGU_LOWMEM_MT", 1) >= 2 && p.W1 > 4) return launch_mfma_mt<R, KS, T, 2>(p, st);
-  return launch_mfma_mt<R, KS, T, 1>(p, st);
+  const bool mt2 = env_int("LGU_LOWMEM_MT", 1) >= 2 && p.W1 > 4;
+  const bool zo_on = env_int("LGU_LOWMEM_ZO", 1) != 0;
+  int l0 = 0;
+  while (l0 < p.L) {
+    const bool zo = zo_on && p.offset[l0] == nullptr;
+    int l1 = l0 + 1;
+    while (l1 < p.L && (zo_on && p.offset[l1] == nullptr) == zo) l1++;
+    MmParams q = p;
+    q.L = l1 - l0;
+    q.lbase = p.lbase + l0;
+    q.lvl0 = p.lvl0 + l0;
+    for (int l = 0; l < MM_MAXL; l++) {
+      const bool on = l < q.L;
+      q.fmap2[l] = on ? p.fmap2[l0 + l] : nullptr;
+      q.offset[l] = on ? p.offset[l0 + l] : nullptr;
+      q.H2[l] = on ? p.H2[l0 + l] : 0;
+      q.W2[l] = on ? p.W2[l0 + l] : 0;
+    }
+    int rc;
+    if (zo) rc = mt2 ? launch_mfma_mt<R, KS, T, 2, true>(q, st) : launch_mfma_mt<R, KS, T, 1, true>(q, st);
+    else rc = mt2 ? launch_mfma_mt<R, KS, T, 2, false>(q, st) : launch_mfma_mt<R, KS, T, 1, false>(q, st);
+    if (rc != LGU_OK) return rc;
+    l0 = l1;
+  }
+  return LGU_OK;
 }
 
 template <typename T>
@@ -513,6 +574,7 @@ static MmParams single_level(const void* fmap1, const void* fmap2, const float* 
   p.fmap1 = fmap1; p.fmap2[0] = fmap2; p.offset[0] = offset; p.coords = coords; p.corr = corr;
   p.H2[0] = H2; p.W2[0] = W2;
   p.L = 1; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
+  p.lvl0 = 0; p.Ltot = 1;
   return p;
 }
 int lowmem_mfma_dispatch(const _Float16* fmap1, const _Float16* fmap2, const float* coords, float* offset, float* corr,
@@ -547,6 +609,7 @@ static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2,
   p.coords = coords; p.corr = out;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.ii = ii; p.jj = jj;
+  p.lvl0 = 0; p.Ltot = L;
   p.f2_chunked = chunked ? 1 : 0;
   if (B == 0) return LGU_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -589,9 +652,10 @@ int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* f
 extern "C" {
 int lgu_mm_diag_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lgu::g_mm_stamps), &p, sizeof(p)); }
 int lgu_mm_diag_lowmem(const void* fmap1, const void* fmap2, const float* coords, float* offset, float* corr, int B, int S,
-                       int H1, int W1, int H2, int W2, int C, int radius, void* stream) {
-  return lgu::lowmem_mfma_dispatch(static_cast<const _Float16*>(fmap1), static_cast<const _Float16*>(fmap2), coords, offset,
-                                   corr, B, S, H1, W1, H2, W2, C, radius, reinterpret_cast<hipStream_t>(stream));
+                       int H1, int W1, int H2, int W2, int C, int radius, int chunked, void* stream) {
+  lgu::MmParams p = lgu::single_level(fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2);
+  p.f2_chunked = chunked;
+  return lgu::mfma_dispatch<_Float16>(p, C, radius, reinterpret_cast<hipStream_t>(stream));
 }
 }
 #endif

@@ -352,7 +352,7 @@ def lowmem_chunked(fmap):
     k = 8 if fmap.dtype == torch.float16 else 4
     F, H, W, C = fmap.shape
     if C % k != 0:
-        raise RuntimeError("lowmem_chunked: C must be a multiple of %d" % k)
+        raise _lib.UnsupportedShape("lowmem_chunked: C must be a multiple of %d" % k)
     return fmap.view(F, H, W, C // k, k).permute(0, 3, 1, 2, 4).contiguous()
 
 

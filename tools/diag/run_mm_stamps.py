@@ -24,8 +24,13 @@ base = torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, de
 off0 = (4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device=dev))).contiguous()
 vp = ctypes.c_void_p
 names = ["boxes", "lane setup + A + first loads", "sweep", "sampling", "write-out"]
+import sys
+CHUNKED = 0 if (len(sys.argv) > 1 and sys.argv[1] == "channel_last") else 1   # fmap2 layout (production: chunk-planar)
+print("fmap2 layout:", "chunk-planar" if CHUNKED else "channel-last", "| levels 2, 3 with null (zero) offsets, as AltCorrBlock launches them")
 for l in range(4):
     f2 = (torch.randn(B, H >> l, W >> l, C, device=dev) * 0.125).half().contiguous()
+    if CHUNKED:
+        f2 = f2.view(B, H >> l, W >> l, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
     cl = (base / 2 ** l).contiguous()
     corr = torch.empty(B, 1, 7, 7, H, W, device=dev)
     nwg = ((B + 7) // 8) * 8 * ((W + 3) // 4) * ((H + 3) // 4)
@@ -33,8 +38,8 @@ for l in range(4):
     lib.lgu_mm_diag_set_stamps(vp(stamps.data_ptr()))
     for it in range(2):
         stamps.zero_()
-        rc = lib.lgu_mm_diag_lowmem(vp(f1.data_ptr()), vp(f2.data_ptr()), vp(cl.data_ptr()), vp(off0.data_ptr()),
-                                    vp(corr.data_ptr()), B, 1, H, W, H >> l, W >> l, C, 3, None)
+        rc = lib.lgu_mm_diag_lowmem(vp(f1.data_ptr()), vp(f2.data_ptr()), vp(cl.data_ptr()), vp(off0.data_ptr()) if l < 2 else None,
+                                    vp(corr.data_ptr()), B, 1, H, W, H >> l, W >> l, C, 3, CHUNKED, None)
         assert rc == 0, rc
         torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.float64) * 10e-3  # 100 MHz ticks -> microseconds
