@@ -519,6 +519,8 @@ static int launch_mfma_mt(MmParams p, hipStream_t st) {
 // (108 vs 116 us); at 4 waves per CU the latency of the box and sampling phases is exposed and the coarse levels lose
 // (51 vs 37 us, 49 vs 32 us): 229 vs 220 us for the four levels in one launch.
 // LGU_LOWMEM_ZO (debug / A-B only): 0 = zero-offset levels through the general kernel too.
+// (Running the two launches of a call concurrently — the second on a side stream forked and joined with events — was
+// measured and lost: 163.5 vs 146.3 us for config 4; the launches stay in order on the caller's stream.)
 template <int R, int KS, typename T>
 static int launch_mfma(const MmParams& p, hipStream_t st) {
   const bool mt2 = env_int("LGU_LOWMEM_MT", 1) >= 2 && p.W1 > 4;
