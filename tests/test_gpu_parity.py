@@ -605,6 +605,62 @@ def test_large_edge_counts_stereo_and_frontend_cap(lgu, E):
     assert torch.equal(c0.view(E, 49, H1, W1), out[:, :49])
 
 
+@pytest.mark.parametrize("probe", [False, True])
+def test_config3_forty_edges_against_the_oracle(lgu, oracle, probe):
+    """BASELINE config 3 at full size (EuRoC stereo: E = 40 edges of 48x64, L = 4, r = 3, 2 GB of pyramid) through the
+    production path (tiled pyramid, lean kernel, probe fused or not): the first, a middle and the LAST edge (highest
+    addresses) against the C oracle — the reference's per-level kernels composed as corr.py:88-109 does."""
+    torch.manual_seed(40)
+    E, H1, W1, L, r = 40, 48, 64, 4, 3
+    vols = [torch.randn(E, H1, W1, H1 >> l, W1 >> l, device="cuda") for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H1, device="cuda").float(), torch.arange(W1, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys])[None] + 3 * torch.randn(E, 2, H1, W1, device="cuda")).contiguous()
+    o0 = 4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda"))
+    o1 = (4 * torch.tanh(torch.randn(E, H1, W1, 7, 7, 2, device="cuda")) + o0) / 2
+    sel = [0, 17, E - 1]
+    host_in = ([host(v[sel]) for v in vols], host(coords[sel]), [host(o0[sel]).copy(), host(o1[sel]).copy(), None, None])
+    tv = [lgu.ops.volume_retile(v) for v in vols]
+    hw = [(H1 >> l, W1 >> l) for l in range(L)]
+    got = lgu.ops.defcorr_pyramid_forward(tv, coords, [o0, o1, None, None], r, probe=probe, tiled=True, level_hw=hw)
+    pv, pc, po = host_in
+    if probe:   # corr.py:94-99: 3x3 plain sample of level 1, unbiased variance, sigmoid, offset[1] *= mask
+        pr, = oracle.corr_index_forward(pv[1], (pc / 2).astype(np.float32), 1)
+        var = torch.var(torch.from_numpy(pr).permute(0, 3, 4, 1, 2), dim=[3, 4])
+        po[1] = (po[1] * torch.sigmoid(var).numpy().reshape(len(sel), H1, W1, 1, 1, 1)).astype(np.float32)
+    want = oracle.defcorr_pyramid_forward(pv, pc, po, r)
+    assert np.abs(host(got[sel]) - want).max() <= (2e-5 if probe else 1e-5)
+    if probe:   # the persistent offset[1] *= mask landed in the caller's tensor
+        assert np.abs(host(o1[sel]) - po[1]).max() <= 1e-5
+
+
+def test_config5_shard_of_250_edges_against_the_oracle(lgu, oracle):
+    """BASELINE config 5's per-GPU shard (250 edges over 40 frames of 60x80x128 half feature maps, all levels, frame
+    buffers read in place, chunk-planar target maps = what ShardedAltCorr launches): the first and the LAST edge against
+    the C oracle of lowMem_defSample on the float copies, level by level (incl. the reference's offset[b*n] indexing:
+    every edge reads edge 0's offsets)."""
+    torch.manual_seed(18)
+    F_, H, W, C, L, E = 40, 60, 80, 128, 4, 250
+    frames = [(torch.randn(F_, H >> l, W >> l, C, device="cuda") * 0.125).half() for l in range(L)]
+    ii = torch.randint(0, F_, (E,), device="cuda")
+    jj = torch.randint(0, F_, (E,), device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(E, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = (4 * torch.tanh(torch.randn(1, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    o1 = ((4 * torch.tanh(torch.randn(1, H, W, 7, 7, 2, device="cuda")) + o0) / 2).contiguous()
+    o0_h, o1_h = host(o0).copy(), host(o1).copy()
+    out = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], [lgu.ops.lowmem_chunked(f) for f in frames], coords,
+                                               [o0, o1, None, None], 3, ii=ii, jj=jj, chunked=True)
+    assert out.shape == (E, 1, 196, H, W) and torch.isfinite(out).all()
+    zero = np.zeros_like(o0_h)
+    for e in (0, E - 1):
+        f1 = host(frames[0][ii[e]].float())[None]
+        for l, off in enumerate((o0_h, o1_h, zero, zero)):
+            f2 = host(frames[l][jj[e]].float())[None]
+            want, = oracle.lowMem_defSample(f1, f2, (host(coords[e:e + 1]) / 2 ** l).astype(np.float32), off.copy(), 3)
+            got = host(out[e, 0, 49 * l:49 * (l + 1)]).reshape(want.shape[2:])
+            assert np.abs(got - want[0, 0]).max() <= 1e-5, (e, l)
+
+
 def test_full_size_properties(lgu):
     """BASELINE cfg2 size (E=20, 48x64, L=4, r=3): size-independent properties instead of
     a full oracle run — linearity in the volume, zero-offset == plain sampler, variant
