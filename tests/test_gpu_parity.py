@@ -661,6 +661,63 @@ def test_config5_shard_of_250_edges_against_the_oracle(lgu, oracle):
             assert np.abs(got - want[0, 0]).max() <= 1e-5, (e, l)
 
 
+LEAN_CASES = {
+    # name: (E, H1, W1, H2, W2, sigma): source size H1 x W1 (W1 % 16 != 0: partial last tile), target slices H2 x W2
+    "partial_tile": (2, 20, 27, 48, 64, 3.0),
+    "one_tile_wide": (3, 5, 9, 24, 32, 3.0),          # W1 < 16: a single, partial tile per row; magic divisor 1
+    "border_heavy": (2, 12, 40, 24, 32, 15.0),        # most taps out of bounds
+    "one_row": (1, 1, 33, 48, 64, 3.0),               # H1 = 1: magic divisor 1 for the row -> edge split
+}
+
+
+@pytest.mark.parametrize("mode", ["plain", "coords_last", "slots"])
+@pytest.mark.parametrize("tiled", [True, False])
+@pytest.mark.parametrize("probe", [False, True])
+@pytest.mark.parametrize("name", list(LEAN_CASES))
+def test_lean_production_kernel_against_the_oracle(lgu, oracle, name, probe, tiled, mode):
+    """csrc/defcorr_lean.hip (radius 3, four levels, offsets on levels 0-1) on shapes its fast paths do not see at the
+    BASELINE sizes: partial tiles (pixels beyond the row end are computed on a duplicate of the last pixel and must
+    neither be stored nor — with the probe — scale that pixel's offsets twice), single-tile rows, H1 = 1, border-heavy
+    coords; with planar / interleaved coords and slot-indirected volumes.  Against the C oracle's composition
+    (probe + mask + four levels), offsets' in-place side effects included."""
+    E, H1, W1, H2, W2, sigma = LEAN_CASES[name]
+    rng = np.random.default_rng(700 + list(LEAN_CASES).index(name))
+    vols_np = inputs.volume_pyramid(rng, E, H1, W1, 4, H2, W2)
+    coords_np = ((inputs.grid_coords(rng, E, H1, W1, sigma)) * np.array([W2 / W1, H2 / H1], np.float32).reshape(1, 2, 1, 1)).astype(np.float32)
+    offs_np = inputs.canonical_offsets(rng, E, H1, W1, 4)
+    hw = [(H2 >> l, W2 >> l) for l in range(4)]
+    vols = [dev(v) for v in vols_np]
+    slots = None
+    if mode == "slots":    # volumes live in a larger buffer at permuted slots
+        perm = torch.randperm(E + 2, device="cuda")[:E].to(torch.int32)
+        big = []
+        for v in vols:
+            b = torch.randn((E + 2,) + tuple(v.shape[1:]), device="cuda")
+            b[perm.long()] = v
+            big.append(b)
+        vols, slots = big, perm.contiguous()
+    if tiled:
+        vols = [lgu.ops.volume_retile(v.contiguous()) for v in vols]
+    coords = dev(coords_np)
+    offs = [dev(o) if o is not None else None for o in offs_np]
+    plan = lgu.ops.DefcorrPyramidPlan(vols, offs, 3, probe=probe, tiled=tiled, level_hw=hw if tiled else None,
+                                      coords_last=(mode == "coords_last"), slots=slots)
+    got = plan(coords.permute(0, 2, 3, 1).contiguous() if mode == "coords_last" else coords)
+    po = [o.copy() if o is not None else None for o in offs_np]
+    if probe:
+        pr, = oracle.corr_index_forward(vols_np[1], (coords_np / 2).astype(np.float32), 1)
+        var = torch.var(torch.from_numpy(pr).permute(0, 3, 4, 1, 2), dim=[3, 4])
+        po[1] = (po[1] * torch.sigmoid(var).numpy().reshape(E, H1, W1, 1, 1, 1)).astype(np.float32)
+    want = oracle.defcorr_pyramid_forward(vols_np, coords_np, po, 3)
+    assert np.abs(host(got) - want).max() <= (2e-5 if probe else 1e-5)
+    # in-place side effects: centres zeroed; level-1 offsets scaled ONCE by the mask
+    assert float(offs[0][:, :, :, 3, 3].abs().max()) == 0 and float(offs[1][:, :, :, 3, 3].abs().max()) == 0
+    assert np.abs(host(offs[1]) - po[1]).max() <= 1e-5
+    o0_want = offs_np[0].copy()
+    o0_want[:, :, :, 3, 3] = 0
+    assert np.array_equal(host(offs[0]), o0_want)
+
+
 def test_full_size_properties(lgu):
     """BASELINE cfg2 size (E=20, 48x64, L=4, r=3): size-independent properties instead of
     a full oracle run — linearity in the volume, zero-offset == plain sampler, variant
