@@ -14,10 +14,10 @@
 //
 //   M = pixels (flattened y*W + x, 16 per MFMA tile), N = output channels (98, padded to 112 = 7 tiles),
 //   K = 9 taps x 256 channels = 72 steps of 32.
-// Workgroup = 4 waves x 2 pixel tiles = 128 pixels.  A (pixels) comes straight from the channel-last frame buffers —
+// Workgroup = 4 waves x 2 (or 1) pixel tiles = 128 (64) pixels.  A (pixels) comes straight from the channel-last frame buffers —
 // 16 contiguous bytes per lane, frame ii[e] for channels 0-127 and jj[e] for 128-255, zero outside the image — no
 // gather, no concatenation, no cast.  B (weights) is prepacked on the host in MFMA fragment order, 14 KiB per K step
-// (2 parts x 7 tiles x 1 KiB), streamed into a double-buffered LDS area by LDS-DMA one step ahead and read back
+// (2 parts x 7 tiles x 1 KiB), streamed into a three-slot LDS ring by LDS-DMA two steps ahead and read back
 // lane-linearly.  Output (E, 98, H, W) fp32 with the bias added: a lane owns 4 consecutive pixels of one channel = one
 // 16-byte store.  The residual head (corr.py:219-220: ofs_residual on the 2 x 2 average of that input) is the same
 // kernel over frames pooled once per block, with the input in two half parts as well (template LO).
@@ -27,13 +27,18 @@ namespace lgu {
 
 constexpr int OC_NT = 7;                      // output-channel tiles (<= 112 channels)
 constexpr int OC_CHUNK = 2 * OC_NT * 1024;    // bytes of weight fragments per K step (hi + lo)
-constexpr int OC_WAVES = 4, OC_MT = 2;        // waves per workgroup, pixel tiles per wave
-constexpr int OC_PIX = OC_WAVES * OC_MT * 16; // pixels per workgroup
+constexpr int OC_WAVES = 4;                   // waves per workgroup
+constexpr int OC_RING = 3;                    // LDS ring of weight chunks: chunk s + 2 streams in while chunk s is multiplied
 
 typedef _Float16 oc_half8 __attribute__((ext_vector_type(8)));
 typedef float oc_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned oc_u32x4 __attribute__((ext_vector_type(4)));   // a fragment as the four dwords it is loaded as
 typedef __attribute__((address_space(3))) void oc_lds_void;
 typedef const __attribute__((address_space(1))) void oc_glb_void;
+
+// 16 bytes of zeros in device memory: what a tap outside the image loads (the select is on the ADDRESS, so the loaded
+// fragment is used as it arrives and no wait sits next to the load)
+__device__ oc_u32x4 g_oc_zero[1] = {{0u, 0u, 0u, 0u}};  // not const: keeps it in the global address space (a constant-space pointer would turn the select into flat loads)
 
 struct OffConvParams {
   const _Float16* frames;  // (NF, H, W, C) channel-last, C = 128
@@ -48,9 +53,19 @@ struct OffConvParams {
 
 // LO: the input has two half parts (e.g. 2 x 2 averages of half values, which need up to 24 bits): x = hi + lo and
 // x . W' = hi . whi + hi . wlo + lo . whi + lo . wlo.
-template <bool LO>
+// MT: pixel tiles (of 16) per wave: a workgroup covers 64 MT pixels.  2 for full-resolution maps; 1 when that would
+// leave CUs idle (the residual head runs at half resolution: 10 x 16 workgroups of 128 pixels on 256 CUs).
+//
+// K loop (9 taps x KS steps): the weight chunk of step s + 2 is in flight by LDS-DMA and the pixel fragments of step
+// s + 2 in registers while step s is multiplied — one raw barrier per step, a COUNTED vmcnt in front of it (never 0:
+// __syncthreads() would drain the DMA queue, cdna_hip_programming.md "Pipelining across barriers").  Round 1's form
+// (two buffers, vmcnt(0) + __syncthreads() per step) ran at 28 % of the matrix peak.  Pixel loads are unconditional
+// (zero padding by pointing the lane at a zero fragment), so every wave issues the same number of vector-memory
+// operations per step and the count is exact.
+template <bool LO, int MT>
 __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const OffConvParams p) {
-  extern __shared__ float4 oc_smem[];  // 2 x OC_CHUNK
+  constexpr int PIX = OC_WAVES * MT * 16;
+  extern __shared__ float4 oc_smem[];  // OC_RING x OC_CHUNK
   char* const wbuf = reinterpret_cast<char*>(oc_smem);
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,86 +77,104 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
   const int ksh = p.KS >> 1;  // K steps per frame
 
   // this lane's A-row pixel in each of the wave's tiles
-  int py[OC_MT], px[OC_MT];
-  bool pv[OC_MT];
+  int py[MT], px[MT];
+  bool pv[MT];
 #pragma unroll
-  for (int t = 0; t < OC_MT; t++) {
-    const int pix = blockIdx.x * OC_PIX + (w * OC_MT + t) * 16 + lr;
+  for (int t = 0; t < MT; t++) {
+    const int pix = blockIdx.x * PIX + (w * MT + t) * 16 + lr;
     pv[t] = pix < HW;
-    py[t] = pix / p.W;
-    px[t] = pix - py[t] * p.W;
+    const int pc = pv[t] ? pix : HW - 1;
+    py[t] = pc / p.W;
+    px[t] = pc - py[t] * p.W;
   }
 
-  oc_f32x4 acc[OC_MT][OC_NT];
+  oc_f32x4 acc[MT][OC_NT];
 #pragma unroll
-  for (int t = 0; t < OC_MT; t++)
+  for (int t = 0; t < MT; t++)
 #pragma unroll
     for (int n = 0; n < OC_NT; n++) acc[t][n] = oc_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = 9 * p.KS;
-  // weight chunk `s` -> LDS buffer s & 1: 14 KiB = 3.5 x (256 threads x 16 bytes), contiguous in wpack
-  auto stage = [&](int s) {
+  // weight chunk `s` -> ring slot s % 3: 14 KiB = 3.5 x (256 threads x 16 bytes), contiguous in wpack
+  // (slot = ring slot to fill, s = chunk to read: they differ only past the last step, where the pipeline keeps issuing
+  // so that every step carries the same number of operations; those fills land in a slot nobody reads any more)
+  auto stage = [&](int slot, int s) {
     const char* src = reinterpret_cast<const char*>(p.wpack) + (size_t)s * OC_CHUNK + (size_t)w * 1024 + lane * 16;
-    char* dst = wbuf + (s & 1) * OC_CHUNK + w * 1024;  // wave-uniform; the DMA adds lane * 16
+    char* dst = wbuf + slot * OC_CHUNK + w * 1024;  // wave-uniform; the DMA adds lane * 16
+    // four pieces per wave, branch-free: waves 2, 3 have only three (14 KiB = 3.5 x 4 KiB) and repeat their last one —
+    // the same bytes to the same place.  (A branch around a DMA makes the compiler's wait-count pass lose the counts and
+    // drain the queue before later uses of prefetched registers.)
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (k * 4096 + w * 1024 < OC_CHUNK)
-        __builtin_amdgcn_global_load_lds((oc_glb_void*)(src + k * 4096), (oc_lds_void*)(dst + k * 4096), 16, 0, 0);
+    for (int k = 0; k < 4; k++) {
+      const int kk = (k * 4096 + w * 1024 < OC_CHUNK) ? k : k - 1;
+      __builtin_amdgcn_global_load_lds((oc_glb_void*)(src + kk * 4096), (oc_lds_void*)(dst + kk * 4096), 16, 0, 0);
+    }
   };
-  auto load_a = [&](int s, oc_half8 (&a)[OC_MT], oc_half8 (&al)[OC_MT]) {
+  // pixel fragments of step s: always loaded — taps outside the image read the zero fragment
+  auto load_a = [&](int s, oc_u32x4 (&a)[MT], oc_u32x4 (&al)[MT]) {
     const int tap = s / p.KS, ks = s - tap * p.KS;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
     const size_t fo = (ks < ksh ? o1 : o2) + (ks < ksh ? ks : ks - ksh) * 32 + kg * 8;
 #pragma unroll
-    for (int t = 0; t < OC_MT; t++) {
+    for (int t = 0; t < MT; t++) {
       const int yy = py[t] + dy, xx = px[t] + dx;
       const bool ok = pv[t] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      a[t] = oc_half8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (LO) al[t] = a[t];
-      if (ok) {
-        const size_t off = fo + ((size_t)yy * p.W + xx) * p.C;
-        a[t] = *reinterpret_cast<const oc_half8*>(p.frames + off);
-        if (LO) al[t] = *reinterpret_cast<const oc_half8*>(p.frames_lo + off);
-      }
+      const size_t off = fo + ((size_t)(ok ? yy : 0) * p.W + (ok ? xx : 0)) * p.C;
+      a[t] = *(ok ? reinterpret_cast<const oc_u32x4*>(p.frames + off) : g_oc_zero);
+      if (LO) al[t] = *(ok ? reinterpret_cast<const oc_u32x4*>(p.frames_lo + off) : g_oc_zero);
     }
   };
 
-  oc_half8 a_cur[OC_MT], a_nxt[OC_MT], l_cur[OC_MT], l_nxt[OC_MT];
-  stage(0);
-  load_a(0, a_cur, l_cur);
-  for (int s = 0; s < nsteps; s++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk s has landed (this wave's part) and a_cur is here
-    __syncthreads();                                  // ... everyone's part; buffer (s + 1) & 1 is no longer read
-    if (s + 1 < nsteps) {
-      stage(s + 1);
-      load_a(s + 1, a_nxt, l_nxt);
-    }
-    const char* const wb = wbuf + (s & 1) * OC_CHUNK + lane * 16;
+  // three register sets in fixed roles (step s uses set s % 3): no copies between them — a copy would have to wait for
+  // the youngest load, i.e. drain the DMA queue behind it
+  oc_u32x4 ar[OC_RING][MT], lr_[OC_RING][MT];
+  stage(0, 0);
+  load_a(0, ar[0], lr_[0]);
+  stage(1, 1);
+  load_a(1, ar[1], lr_[1]);
+  auto step = [&](int s, int slot, oc_u32x4 (&a)[MT], oc_u32x4 (&al)[MT], oc_u32x4 (&an)[MT], oc_u32x4 (&aln)[MT]) __attribute__((always_inline)) {
+    // chunk s has landed (this wave's part): everything older than the DMA of chunk s + 1 and the pixel loads of
+    // step s + 1 is complete when at most that many operations are outstanding (loads return in order)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + MT * (LO ? 2 : 1)) : "memory");
+    __builtin_amdgcn_s_barrier();  // ... everyone's part; ring slot (s + 2) % 3 = (s - 1) % 3 is no longer read
+    const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;   // past the end: refetch the last chunk (see stage)
+    stage(slot == 0 ? 2 : slot - 1, s2);
+    load_a(s2, an, aln);
+    const char* const wb = wbuf + slot * OC_CHUNK + lane * 16;
 #pragma unroll
     for (int n = 0; n < OC_NT; n++) {
       const oc_half8 bh = *reinterpret_cast<const oc_half8*>(wb + n * 1024);
       const oc_half8 bl = *reinterpret_cast<const oc_half8*>(wb + (OC_NT + n) * 1024);
 #pragma unroll
-      for (int t = 0; t < OC_MT; t++) {
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[t], bh, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[t], bl, acc[t][n], 0, 0, 0);
+      for (int t = 0; t < MT; t++) {
+        const oc_half8 av = __builtin_bit_cast(oc_half8, a[t]);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bh, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bl, acc[t][n], 0, 0, 0);
         if (LO) {
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l_cur[t], bh, acc[t][n], 0, 0, 0);
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l_cur[t], bl, acc[t][n], 0, 0, 0);
+          const oc_half8 alv = __builtin_bit_cast(oc_half8, al[t]);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, bh, acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, bl, acc[t][n], 0, 0, 0);
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < OC_MT; t++) {
-      a_cur[t] = a_nxt[t];
-      if (LO) l_cur[t] = l_nxt[t];
-    }
+  };
+  // nsteps = 9 KS with KS = C / 16 even (host-checked): a multiple of 6.  Six steps per trip: at the loop header the
+  // compiler's wait-count pass loses the counts and drains the queue once (checked in the ISA), so the header is made rare.
+#pragma unroll 1
+  for (int s = 0; s < nsteps; s += 6) {
+    step(s, 0, ar[0], lr_[0], ar[2], lr_[2]);
+    step(s + 1, 1, ar[1], lr_[1], ar[0], lr_[0]);
+    step(s + 2, 2, ar[2], lr_[2], ar[1], lr_[1]);
+    step(s + 3, 0, ar[0], lr_[0], ar[2], lr_[2]);
+    step(s + 4, 1, ar[1], lr_[1], ar[0], lr_[0]);
+    step(s + 5, 2, ar[2], lr_[2], ar[1], lr_[1]);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing fills, before the workgroup's LDS is released
 
   // C layout: lane (kg, lr) holds pixels 4 kg .. 4 kg + 3 of the tile for channel tile*16 + lr
 #pragma unroll
-  for (int t = 0; t < OC_MT; t++) {
-    const int pix0 = blockIdx.x * OC_PIX + (w * OC_MT + t) * 16 + kg * 4;
+  for (int t = 0; t < MT; t++) {
+    const int pix0 = blockIdx.x * PIX + (w * MT + t) * 16 + kg * 4;
 #pragma unroll
     for (int n = 0; n < OC_NT; n++) {
       const int ch = n * 16 + lr;
@@ -179,11 +212,15 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
   p.frames = static_cast<const _Float16*>(frames); p.frames_lo = static_cast<const _Float16*>(frames_lo); p.ii = ii; p.jj = jj;
   p.wpack = static_cast<const _Float16*>(wpack); p.bias = bias; p.out = out;
   p.E = E; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.KS = 2 * C / 32;
-  const dim3 grid((H * W + OC_PIX - 1) / OC_PIX, E);
-  if (frames_lo)
-    hipLaunchKernelGGL(offconv_frames_kernel<true>, grid, dim3(OC_WAVES * kWave), 2 * OC_CHUNK, reinterpret_cast<hipStream_t>(stream), p);
-  else
-    hipLaunchKernelGGL(offconv_frames_kernel<false>, grid, dim3(OC_WAVES * kWave), 2 * OC_CHUNK, reinterpret_cast<hipStream_t>(stream), p);
+  // pixel tiles per wave: 2 (128 pixels per workgroup) unless that leaves fewer than two workgroups per CU
+  const int mt = ((H * W + 127) / 128) * E >= 512 ? 2 : 1;
+  const dim3 grid((H * W + 64 * mt - 1) / (64 * mt), E);
+  const size_t lds = (size_t)OC_RING * OC_CHUNK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LGU_OC(LOV, MTV) hipLaunchKernelGGL((offconv_frames_kernel<LOV, MTV>), grid, dim3(OC_WAVES * kWave), lds, st, p)
+  if (frames_lo) { if (mt == 2) LGU_OC(true, 2); else LGU_OC(true, 1); }
+  else { if (mt == 2) LGU_OC(false, 2); else LGU_OC(false, 1); }
+#undef LGU_OC
   return launch_status();
 }
 
