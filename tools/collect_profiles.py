@@ -77,11 +77,14 @@ for r in csv.DictReader(open(newest("prof_lm", "kernel_trace"))):
         per.setdefault(n.split("(")[0].replace("void ", ""), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 def level_means(v):
     # tools/prof_lowmem.py: levels 0..3 with n launches each, then (matrix-core kernel only) 5 launches of all levels fused
+    # (round 2: a fused call is two kernels — levels with offsets on the general kernel, zero-offset levels on the ZO
+    # instantiation, which therefore shows up with its 5 fused launches only)
     fused = None
-    if len(v) % 4 == 1 or len(v) == 25:
+    if len(v) % 4 == 1 or len(v) == 25 or len(v) < 8:
         v, fused = v[:-5], v[-5:]
     n = len(v) // 4
-    return [round(sum(v[i * n:(i + 1) * n]) / n, 2) for i in range(4)], (round(sum(fused) / len(fused), 2) if fused else None)
+    per_level = [round(sum(v[i * n:(i + 1) * n]) / n, 2) for i in range(4)] if n else []
+    return per_level, (round(sum(fused) / len(fused), 2) if fused else None)
 
 
 lowmem = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/prof_lowmem.py",
@@ -89,7 +92,7 @@ lowmem = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- py
           "kernel_us_per_launch_in_order": per,
           "level_totals_us": {n: level_means(v)[0] for n, v in per.items()},
           "all_levels_in_one_launch_us": {n: level_means(v)[1] for n, v in per.items() if level_means(v)[1] is not None}}
-lowmem["four_level_total_us"] = {n: round(sum(v), 1) for n, v in lowmem["level_totals_us"].items()}
+lowmem["four_level_total_us"] = {n: round(sum(v), 1) for n, v in lowmem["level_totals_us"].items() if v}
 lowmem["Mpix_edges_per_s"] = {n: round(16 * 60 * 80 / t, 1) for n, t in lowmem["four_level_total_us"].items()}
 lowmem["Mpix_edges_per_s_one_launch"] = {n: round(16 * 60 * 80 / t, 1) for n, t in lowmem["all_levels_in_one_launch_us"].items()}
 json.dump(lowmem, open(os.path.join(P, "%s_lowmem_kernels.json" % tag), "w"), indent=1)
