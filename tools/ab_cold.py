@@ -63,11 +63,14 @@ for rnd in range(rounds):
     for i, c in enumerate(configs):
         select(c)
         step = sets.stepper(plans[(c["layout"], c["probe"])], sets.out, True)
+        sets.restore_offsets()
         for j in range(8):
             step(j)
+        # EVERY block starts from the original offsets: a probe-on launch scales offset[1] in place (corr.py:99), and
+        # probe-off configurations timed after it would otherwise sample a shrunken level-1 footprint (fewer lines, up to
+        # 15 % faster: the first A/B files of round 2 carry that bias in their probe-off rows, see profiles/README.md)
         n = 16 if c["probe"] else 100
-        pre = sets.restore_offsets if c["probe"] else None
-        times[i] += [x * 1e3 for x in bench.time_blocks(step, n, 6 if c["probe"] else 1, pre)]
+        times[i] += [x * 1e3 for x in bench.time_blocks(step, n, 6 if c["probe"] else 1, sets.restore_offsets)]
 for i, c in enumerate(configs):
     t = np.array(times[i])
     print(json.dumps(dict(c, us_median=round(float(np.median(t)), 2), us_min=round(float(t.min()), 2),
