@@ -262,17 +262,21 @@ class DefcorrSets:
                                                   tiled=tiled, level_hw=self.level_hw if tiled else None, out_format=out_format))
         return ps
 
-    def restore_offsets(self):
+    def restore_offsets(self, only=None):
         """The fused probe scales offset[1] in place on every call (corr.py:99, persistent); a CorrBlock lives for 8-16
         lookups, so timed blocks of probe-on launches restart from the original offsets."""
-        for s in range(self.nsets):
+        for s in (range(self.nsets) if only is None else (only,)):
             self.offs[s][1].copy_(self.offs1_saved[s])
 
-    def stepper(self, plans, out, cold=True):
+    def stepper(self, plans, out, cold=True, probe=False):
+        """probe=True: a set's offsets are restored before every 16th use of that set (a 24 MB copy per 16 lookups, as a
+        new CorrBlock would bring fresh offsets), so that a long run does not drive offset[1] to zero."""
         n = self.nsets if cold else 1
 
         def step(i):
             s = i % n
+            if probe and (i // n) % 16 == 0:
+                self.restore_offsets(only=s)
             plans[s](self.coords[s], out=out)
         return step
 
@@ -616,7 +620,7 @@ def main():
         out = ops._pyr_out(args.out_format, E, L * (2 * R + 1) ** 2, H1, W1, dev, None)
     # --probe: the level-1 uncertainty probe, variance, sigmoid and the stateful offset[1] *= mask of corr.py:94-99 run
     # inside the same launch
-    step = sets.stepper(plans, out, cold)
+    step = sets.stepper(plans, out, cold, probe=args.probe)
 
     def barrier():
         if use_dist:
