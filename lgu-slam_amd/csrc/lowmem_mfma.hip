@@ -346,6 +346,8 @@ __global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma
       }
     const int ngx = (UX1 - UX0 + 16) >> 4;  // groups of 16 positions per window row
     const int nit = ngx * (UY1 - UY0 + 1);
+    // The window is swept column of groups by column of groups (rows innermost): whether this lane's position lies in
+    // the box columns of its four pixels then changes only ngx times per sweep, not every group.
     // k-step s of lane (lg, lx) holds channels CPS s + EPL lg .. + EPL - 1 of position gx0 + lx
     const size_t bstep = p.f2_chunked ? (size_t)4 * H2 * W2 * EPL : (size_t)CPS;  // elements from k-step s to s + 1
     auto bptr = [&](int y, int gx0) {
@@ -364,12 +366,20 @@ __global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma
         const T* p = bptr(yl, gxl);
 #pragma unroll
         for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + bstep * s);
-        gxl += 16;
-        if (gxl > UX1) { gxl = UX0; yl++; }
+        yl++;
+        if (yl > UY1) { yl = UY0; gxl += 16; }
       }
     }
     MM_STAMP(2);
     int y = UY0, gx0 = UX0;   // compute cursor
+    bool xok[MT][4];          // position gx0 + lx inside the box columns of pixel 4 lg + r (lane masks, per column of groups)
+    auto column = [&](int g0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) xok[m][r] = (unsigned)(g0 + sxv[m][r]) < (unsigned)sbw[m][r];
+    };
+    column(UX0);
     for (int it = 0; it < nit; it += MM_PF) {
 #pragma unroll
       for (int j = 0; j < MM_PF; j++) {
@@ -385,19 +395,23 @@ __global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma
             const T* p = bptr(yl, gxl);
 #pragma unroll
             for (int s = 0; s < KS; s++) bq[j][s] = *reinterpret_cast<const frag*>(p + bstep * s);
-            gxl += 16;
-            if (gxl > UX1) { gxl = UX0; yl++; }
+            yl++;
+            if (yl > UY1) { yl = UY0; gxl += 16; }
           }
           const int yg = y * BOXP + gx0;
 #pragma unroll
           for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-              const unsigned qx = (unsigned)(gx0 + sxv[m][r]), qy = (unsigned)(y - sylo[m][r]);
-              if (qx < (unsigned)sbw[m][r] && qy < (unsigned)sbh[m][r]) patch[sbase[m][r] + yg] = d[m][r];
+              const unsigned qy = (unsigned)(y - sylo[m][r]);
+              if (xok[m][r] && qy < (unsigned)sbh[m][r]) patch[sbase[m][r] + yg] = d[m][r];
             }
-          gx0 += 16;
-          if (gx0 > UX1) { gx0 = UX0; y++; }
+          y++;
+          if (y > UY1) {  // next column of groups (wave-uniform)
+            y = UY0;
+            gx0 += 16;
+            column(gx0);
+          }
         }
       }
     }
@@ -428,23 +442,34 @@ __global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma
       const int xlo = pk_lo(blo[m][q]), ylo = pk_hi(blo[m][q]);
       const bool has_patch = (bwh[m][q] & 0xff) != 0, fallback = (bwh[m][q] >> 16) != 0;
       const float* const Dp = patch + (m * MM_BP + q * 4 + lg) * PP;
+      // zero-offset levels: one sample position per pixel — floor, fraction and the four weights once per pass
+      // (the products and their order are bilerp()'s)
+      const float zfx = floorf(cvv[m][q].x), zfy = floorf(cvv[m][q].y);
+      const float zdx = cvv[m][q].x - zfx, zdy = cvv[m][q].y - zfy;
+      const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
 #pragma unroll
       for (int i = 0; i < TI; i++) {
         const bool tv = pv && lx + 16 * i < NT;
-        const float xs = ZO ? cvv[m][q].x : cvv[m][q].x + o0[m][q][ZO ? 0 : i].x;
-        const float ys = ZO ? cvv[m][q].y : cvv[m][q].y + o0[m][q][ZO ? 0 : i].y;
-        const float fxs = floorf(xs), fys = floorf(ys);
-        const float dx = xs - fxs, dy = ys - fys;  // :87-88
+        float fxs, fys, dx, dy;
+        if constexpr (ZO) {
+          fxs = zfx; fys = zfy; dx = zdx; dy = zdy;
+        } else {
+          const float xs = cvv[m][q].x + o0[m][q][i].x, ys = cvv[m][q].y + o0[m][q][i].y;
+          fxs = floorf(xs); fys = floorf(ys);
+          dx = xs - fxs; dy = ys - fys;  // :87-88
+        }
         const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
-        const bool b11 = in_bounds(h2, w2, H2, W2), b21 = in_bounds(h2, w2 + 1, H2, W2);
-        const bool b12 = in_bounds(h2 + 1, w2, H2, W2), b22 = in_bounds(h2 + 1, w2 + 1, H2, W2);
+        // per-axis range checks (one unsigned compare each), combined per corner
+        const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
+        const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
+        const bool b11 = by0 && bx0, b21 = by0 && bx1, b12 = by1 && bx0, b22 = by1 && bx1;
         float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
         if (tv && has_patch) {
           // the four corners are read unconditionally (two 8-byte LDS reads) and the per-corner zero padding is a
           // select: an in-bounds corner always lies inside the pixel's box, so its entry is where the index says; the
           // others read whatever is there (inside the LDS allocation: MM_GUARD floats in front of the patches cover a
           // top-left one row / column before the box, the box table behind them covers the bottom-right overshoot)
-          const int idx = (b11 || b21 || b12 || b22) ? (h2 - ylo) * BOXP + (w2 - xlo) : 0;
+          const int idx = ((by0 || by1) && (bx0 || bx1)) ? (h2 - ylo) * BOXP + (w2 - xlo) : 0;
           const float* D = Dp + idx;
           const float d0 = D[0], d1 = D[1], d2 = D[BOXP], d3 = D[BOXP + 1];
           q11 = b11 ? d0 : 0.f;
@@ -457,7 +482,8 @@ __global__ __launch_bounds__(kWave, ZO ? 4 : (MT == 1 ? 2 : 1)) void lowmem_mfma
                                           p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
           q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
         }
-        res[m][q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
+        if constexpr (ZO) res[m][q][i] = q11 * zw11 + q21 * zw21 + q12 * zw12 + q22 * zw22;
+        else res[m][q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
       }
     }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
