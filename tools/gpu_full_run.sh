@@ -20,7 +20,7 @@ timeout -k 10 300 python bench.py --workload lowmem --edges 16 > gpurun_out/benc
 timeout -k 10 300 python bench.py --workload backend --steps 10 --warmup 2 > gpurun_out/bench_backend.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/ab_cold.py 0,7,6 6 tiled,rowmajor 0,1 > gpurun_out/ab_final.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/ab_final.jsonl
-timeout -k 10 300 python tools/ab_lowmem.py 1,2 > gpurun_out/ab_lowmem.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python tools/ab_lowmem.py 1,1:c,2:c > gpurun_out/ab_lowmem.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/e2e_calls.py > gpurun_out/e2e_calls.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 { timeout -k 10 200 python tools/prof_init.py 20 f32 && timeout -k 10 200 python tools/prof_init.py 20 half; } 2> gpurun_out/bench.err | grep "CorrBlock.__init__" > gpurun_out/prof_init.txt || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/prof_init.txt
