@@ -859,7 +859,7 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   const int nt_ = (2 * R + 1) * (2 * R + 1);
   constexpr int tpx = KIND >= 11 ? 16 : KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
-                     : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1)) + (size_t)env_int("LGU_LDS_PAD", 0);  // pad: occupancy experiments (tools/ab_cold.py)
+                     : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1)) + lds_pad();  // pad: occupancy experiments (tools/ab_cold.py)
   // if constexpr: only the kernel of this KIND is instantiated
   void (*kern)(const PyrParams);
   if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;

@@ -363,7 +363,7 @@ int lean_pyramid_forward(const float* const* volumes, const float* coords, float
     return LGU_E_UNSUPPORTED;
   for (int l = 0; l < NL; l++)
     if ((unsigned long long)g.ssz[l] * 4 >= (1ull << 31)) return LGU_E_UNSUPPORTED;
-  const size_t lds = sizeof(float) * CH * PITCH + (size_t)env_int("LGU_LDS_PAD", 0);  // pad: occupancy experiments only
+  const size_t lds = sizeof(float) * CH * PITCH + lds_pad();  // pad: occupancy experiments only
   const int remap = 1;
   const unsigned mt = magic_u32(tiles_per_row), mh = magic_u32((unsigned)H1);
 #define LGU_LEAN(PR, TL)                                                                                               \

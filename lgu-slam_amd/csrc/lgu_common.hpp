@@ -104,4 +104,10 @@ inline int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
+// LGU_LDS_PAD (occupancy experiments only, tools/ab_cold.py): extra dynamic LDS per workgroup, clamped to [0, 96 KiB]
+inline size_t lds_pad() {
+  const int v = env_int("LGU_LDS_PAD", 0);
+  return (size_t)(v < 0 ? 0 : (v > 96 * 1024 ? 96 * 1024 : v));
+}
+
 }  // namespace lgu

@@ -17,7 +17,8 @@ import lgu_slam_amd  # noqa: E402
 ops = lgu_slam_amd.ops
 dev = torch.device("cuda:0")
 # variant[:prefetch distance], e.g. "0:0,0:48,6"
-# fourth field: LGU_LDS_PAD (extra LDS bytes per workgroup: limits workgroups per CU); third field: LGU_LEAN_W (launch bound of the lean kernel: 8 or 6 waves per SIMD)
+# fourth field: LGU_LDS_PAD (extra LDS bytes per workgroup: limits workgroups per CU); the third field is unused (it
+# selected the launch bound of the lean kernel while both bounds were built)
 def _spec(v):
     f = [int(x) for x in v.split(":")]
     return tuple(f + [-1, -1, 0][len(f) - 1:])
@@ -38,10 +39,6 @@ def select(c):
     else:
         os.environ.pop("LGU_DEFCORR_PF", None)
     os.environ["LGU_LDS_PAD"] = str(c["pad"])
-    if c["lw"] >= 0:
-        os.environ["LGU_LEAN_W"] = str(c["lw"])
-    else:
-        os.environ.pop("LGU_LEAN_W", None)
 
 
 plans = {(lay, pr): sets.plans(lay, pr, "planar") for lay in layouts for pr in probes}
