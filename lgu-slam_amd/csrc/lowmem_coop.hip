@@ -1,0 +1,577 @@
+// lowmem_coop.hip — on-the-fly deformable correlation from HALF feature maps on the matrix cores, with the swept
+// windows of the target map SHARED by the four waves of a workgroup and all pyramid levels served by one wave life.
+//
+// Same operator and same patch formulation as lowmem_mfma.hip (reference kernels replaced:
+// offersample_LGS/lowMem_defSample.cu:27-134, src/altcorr_kernel.cu:27-149; per-level loop of AltCorrBlock.corr_fn,
+// droid_slam/modules/corr.py:192-213): a pixel's 49 taps only need its LOCAL correlation patch
+//     D_p[y2][x2] = sum_c fmap1[p][c] * fmap2[y2][x2][c]      over its tap box (<= 16 x 16 positions),
+// computed with v_mfma_f32_16x16x32_f16 and sampled from LDS with the reference's per-corner zero padding.
+//
+// What bounds the one-wave-per-block kernel is the rate at which window positions reach the matrix cores (L2 -> CU:
+// 11 KB per pixel at level 0, each 16-position fragment feeding 16 pixels).  Here
+//   * a workgroup = 4 waves = a 4 x 16 pixel tile (four 4 x 4 sub-blocks side by side).  The union window of the tile is
+//     only ~1.5 x that of one sub-block (tap boxes are ~14 wide whatever the tile), and its rows are dealt to the four
+//     waves: every wave keeps the fmap1 fragments of ALL 64 pixels in registers and multiplies each position fragment
+//     it loads with the four sub-blocks -> 64 pixels per fragment instead of 16 (4.3 KB per pixel at level 0), with
+//     no staging of the window in LDS and no more loads per wave;
+//   * the MFMA is issued with the POSITIONS as rows (A) and the pixels as columns (B): a lane then holds four
+//     x-adjacent positions of ONE pixel, so the scatter into the pixel's patch is two 8-byte LDS stores with one row
+//     and two column range checks (the pixel-rows form needs four 4-byte stores to four different pixels, each with
+//     its own checks: ~45 VALU instructions per fragment).  Patches are 16 rows x 18 columns with the origin at the
+//     box corner rounded down to an even column, so the pairs stay 8-byte aligned;
+//   * one wave life serves every level of the call: coords and the fmap1 fragments are loaded once, and the latency of
+//     one level's phases overlaps the other workgroup of the CU (2 workgroups = 8 waves per CU, 75 KB of LDS each).
+// Per level: boxes (own sub-block) | barrier | cooperative sweep | barrier | sampling + write-out (own sub-block).
+// Half products are exact in fp32 and the accumulation is fp32: the result differs from the `.float()` call site by
+// summation order only (tests: 1e-5).  Boxes wider than 16 (|offset| >= 4: never produced by corr.py:126-131) take the
+// per-tap fallback, as in lowmem_mfma.hip.
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+typedef _Float16 cohalf8 __attribute__((ext_vector_type(8)));
+typedef float cof32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CO_SB = 4;                       // 4 x 4 sub-blocks (= waves) per workgroup
+constexpr int CO_NPX = 16 * CO_SB;             // pixels per workgroup
+constexpr int CO_BOXP = 18;                    // patch row pitch: 16 columns + the even-alignment slack, pairs 8-byte aligned
+constexpr int CO_PP = 16 * CO_BOXP + 2;        // floats per patch (+2: consecutive pixels start 8 banks apart)
+constexpr int CO_GUARD = 20;                   // floats in front of the patches (>= CO_BOXP + 1): see the sampling phase
+constexpr int CO_OUTP = 20;                    // output transpose pitch
+constexpr int CO_MAXL = 4;
+constexpr int CO_LDS_FLOATS = CO_GUARD + CO_NPX * CO_PP + CO_NPX * 4 + 2 * CO_SB + 8;
+
+struct CoParams {
+  const _Float16* fmap1;
+  const _Float16* fmap2[CO_MAXL];
+  float* offset[CO_MAXL];   // null = zero offsets for that level
+  const float* coords;
+  float* corr;
+  int H2[CO_MAXL], W2[CO_MAXL];
+  int L, B, S, H1, W1, tiles_x, tiles_y, xcd_map, vec_out;
+  int lbase, lvl0, Ltot;
+  int f2_chunked;
+  int ngroups, gl0[CO_MAXL + 1];  // work units = (level group, edge, tile): group k serves levels gl0[k] .. gl0[k + 1] - 1
+  const long long* ii;
+  const long long* jj;
+};
+
+// the four corner dots of one tap straight from memory (boxes larger than the patch)
+__device__ __noinline__ float4 co_corner_dots(const _Float16* f1p, const _Float16* F2, ptrdiff_t pos11, int C, int W2, int mask,
+                                              ptrdiff_t pstride, ptrdiff_t cstride) {
+  float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+  auto dot = [](const cohalf8& f, const cohalf8& a, float s) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
+    return s;
+  };
+  for (int c = 0; c < C; c += 8) {
+    const cohalf8 f = *reinterpret_cast<const cohalf8*>(f1p + c);
+    const _Float16* base = F2 + (ptrdiff_t)(c / 8) * cstride;
+    if (mask & 1) q11 = dot(f, *reinterpret_cast<const cohalf8*>(base + pos11 * pstride), q11);
+    if (mask & 2) q21 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + 1) * pstride), q21);
+    if (mask & 4) q12 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + W2) * pstride), q12);
+    if (mask & 8) q22 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + W2 + 1) * pstride), q22);
+  }
+  return make_float4(q11, q21, q12, q22);
+}
+
+template <bool IS_MIN>
+__device__ __forceinline__ int co_row_pk_reduce(int v) {
+#define LGU_DPP_STEP(ctrl)                                                  \
+  {                                                                         \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false); \
+    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                               \
+  }
+  LGU_DPP_STEP(0xB1)
+  LGU_DPP_STEP(0x4E)
+  LGU_DPP_STEP(0x141)
+  LGU_DPP_STEP(0x140)
+#undef LGU_DPP_STEP
+  return v;
+}
+
+#ifdef LGU_MM_STAMPS
+__device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
+#define CO_STAMP(i)                                                                                                        \
+  do {                                                                                                                     \
+    if (lane == 0 && blockIdx.y == 0) g_co_stamps[((size_t)blockIdx.x * CO_SB + wv) * 32 + lvl * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define CO_STAMP(i)
+#endif
+
+// Lane layout outside the sweep (as in lowmem_mfma.hip): row = lane / 16 is a pixel of the current pass (pass q serves row
+// q of the wave's 4 x 4 sub-block: pixel column = lane row), j = lane % 16 carries the taps j, j + 16, j + 32, j + 48.
+// Inside the sweep lane (lg, lx) holds, per sub-block m, positions gx0 + 4 lg .. + 3 of pixel lx (= row lx / 4, column
+// lx % 4 of the sub-block).
+// Every phase derives its lane indices from a freshly laundered lane id: left alone, the compiler hoists the
+// level-invariant per-lane address arithmetic of ALL phases out of the level loop and shares it between the phases,
+// which keeps ~100 registers live across the sweep and spills the fmap1 fragments to scratch.
+#define CO_FRESH_LANE()                 \
+  int lane = lane0;                     \
+  asm volatile("" : "+v"(lane));        \
+  const int lx = lane & 15, lg = lane >> 4;
+
+template <int R, int KS>
+__global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoParams p) {
+  typedef _Float16 T;
+  typedef cohalf8 frag;
+  constexpr int CPS = 32, EPL = 8;
+  constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
+  constexpr int TI = (NT + 15) / 16;
+  constexpr int CEN = R * RD + R;
+  constexpr int PF = 3;  // position fragments in flight per wave
+  extern __shared__ float smem[];
+  float* const patch = smem + CO_GUARD;                                   // [CO_NPX][CO_PP]
+  int* const pbox = reinterpret_cast<int*>(patch + CO_NPX * CO_PP);       // [CO_NPX][xlo, ylo, bw, bh]
+  int* const swin = pbox + CO_NPX * 4;                                    // [CO_SB][lo, hi] packed
+  const int lane0 = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: scalar
+  const int B = p.B, S = p.S, H1 = p.H1, W1 = p.W1;
+
+  // ---- workgroup -> (level group, edge, tile): groups in launch order, so the long units (levels with offsets) start
+  // first and the short ones fill the tail; the hardware's in-order dispatch to free slots does the balancing ----
+  int b, blk;
+  const int tiles = p.tiles_x * p.tiles_y;
+  const int per_group = (p.xcd_map ? ((B + 7) >> 3) * 8 : B) * tiles;
+  const int grp = (int)blockIdx.x / per_group, item = (int)blockIdx.x - grp * per_group;
+  int lv0 = p.gl0[0], lv1 = p.gl0[1];
+#pragma unroll
+  for (int k = 1; k < CO_MAXL; k++)
+    if (grp == k) { lv0 = p.gl0[k]; lv1 = p.gl0[k + 1]; }
+  if (p.xcd_map) {
+    const int xcd = item & 7, slot = item >> 3;
+    b = (slot / tiles) * 8 + xcd;
+    blk = slot % tiles;
+    if (b >= B) return;  // workgroup-uniform: no barrier is skipped by part of a workgroup
+  } else {
+    b = item / tiles;
+    blk = item % tiles;
+  }
+  const int n = blockIdx.y;
+  const int by = blk / p.tiles_x, bx = blk % p.tiles_x;
+  const int px0 = bx * 16 + wv * 4;  // first pixel column of this wave's sub-block
+  const size_t HW1 = (size_t)H1 * W1;
+  const size_t f1i = p.ii ? (size_t)p.ii[b] : (size_t)b, f2i = p.jj ? (size_t)p.jj[b] : (size_t)b;
+  const T* const F1 = p.fmap1 + f1i * HW1 * C;
+  const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
+
+  // ---- once per wave life: coords of the own sub-block, fmap1 fragments of the whole tile ----
+  float2 cv0[4];
+  frag a[CO_SB][KS];
+  {
+    CO_FRESH_LANE();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int h1 = by * 4 + q, w1r = px0 + lg;
+      const bool pv = h1 < H1 && w1r < W1;
+      cv0[q] = cbase[pv ? (size_t)h1 * W1 + w1r : 0];
+    }
+  }
+
+  for (int lvl = lv0; lvl < lv1; lvl++) {
+    const T* fmap2 = p.fmap2[0];
+    float* offset = p.offset[0];
+    int H2 = p.H2[0], W2 = p.W2[0];
+#pragma unroll
+    for (int l = 1; l < CO_MAXL; l++)
+      if (lvl == l) { fmap2 = p.fmap2[l]; offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
+    const float cscale = __builtin_ldexpf(1.0f, -(p.lbase + lvl));
+    const T* const F2 = fmap2 + f2i * H2 * W2 * C;
+    // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets
+    float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+    const bool zo = obase == nullptr;  // workgroup-uniform
+
+    // offsets of the own sub-block: loaded twice per level (for the boxes, and again behind the sweep for the sampling —
+    // the second read hits L2) instead of holding 32 registers across the sweep
+    auto load_offsets = [&](float2 (&o0)[4][TI], int lx, int lg) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h1 = by * 4 + q, w1r = px0 + lg;
+        const bool pv = h1 < H1 && w1r < W1;
+        const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+          const int t = lx + 16 * i;
+          o0[q][i] = make_float2(0.f, 0.f);
+          if (!zo && pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
+        }
+      }
+    };
+
+    // ---- phase 0: sample positions and tap boxes of the own sub-block ----
+    {
+      CO_FRESH_LANE();
+      CO_STAMP(0);
+      int tix[TI], tiy[TI];
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const int t = lx + 16 * i;
+        tix[i] = t / RD;
+        tiy[i] = t - tix[i] * RD;
+      }
+      float2 o0[4][TI];
+      load_offsets(o0, lx, lg);
+      if (lvl == lv0) {  // fmap1 fragments of the whole tile, requested behind the offsets (loads return in order: the boxes must not wait for these 16 KB)
+#pragma unroll
+        for (int m = 0; m < CO_SB; m++) {
+          int h1 = by * 4 + (lx >> 2), w1 = bx * 16 + m * 4 + (lx & 3);
+          h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
+          const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
+#pragma unroll
+          for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
+        }
+      }
+      if (!zo) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int h1 = by * 4 + q, w1r = px0 + lg;
+          constexpr int ci = CEN / 16;
+          if (lx == CEN % 16 && h1 < H1 && w1r < W1) {
+            if ((__builtin_bit_cast(unsigned, o0[q][ci].x) | __builtin_bit_cast(unsigned, o0[q][ci].y)) != 0u)
+              reinterpret_cast<float2*>(obase + ((size_t)h1 * W1 + w1r) * NT * 2)[CEN] = make_float2(0.f, 0.f);
+            o0[q][ci] = make_float2(0.f, 0.f);
+          }
+        }
+      }
+      int ulo = 0x7fff7fff, uhi = (int)0x80008000;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h1 = by * 4 + q, w1r = px0 + lg;
+        const bool pv = h1 < H1 && w1r < W1;
+        const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
+        int lo = 0x7fff7fff, hi = (int)0x80008000;
+        if (zo) {
+          // taps i, j = -R..R at floor(c) + (i, j), corners one further: the lattice [f - R, f + R + 1]^2 clipped to the map
+          const int fx = (int)floorf(cx), fy = (int)floorf(cy);
+          const int xa = fx - R > 0 ? fx - R : 0, xb = fx + R + 1 < W2 ? fx + R + 1 : W2 - 1;
+          const int ya = fy - R > 0 ? fy - R : 0, yb = fy + R + 1 < H2 ? fy + R + 1 : H2 - 1;
+          if (pv && xa <= xb && ya <= yb) { lo = pk16(xa, ya); hi = pk16(xb, yb); }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TI; i++) {
+            const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;  // :82-83
+            const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
+            const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
+            const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
+            const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
+            lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
+            hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+          }
+          lo = co_row_pk_reduce<true>(lo);
+          hi = co_row_pk_reduce<false>(hi);
+        }
+        const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
+        const bool any = xhi >= xlo && yhi >= ylo;
+        const bool boxed = any && xhi - xlo < 16 && yhi - ylo < 16;
+        ulo = boxed ? pk_min(ulo, lo) : ulo;
+        uhi = boxed ? pk_max(uhi, hi) : uhi;
+        if (lx == 0) {  // box table: (bw, bh) of a patch; (-1, 0) = box larger than a patch (per-tap fallback); (0, 0) = nothing to sample
+          int* pb = pbox + (wv * 16 + q * 4 + lg) * 4;
+          pb[0] = xlo; pb[1] = ylo;
+          pb[2] = boxed ? xhi - xlo + 1 : (any ? -1 : 0);
+          pb[3] = boxed ? yhi - ylo + 1 : 0;
+        }
+      }
+      ulo = pk_min(pk_min(__builtin_amdgcn_readlane(ulo, 0), __builtin_amdgcn_readlane(ulo, 16)),
+                   pk_min(__builtin_amdgcn_readlane(ulo, 32), __builtin_amdgcn_readlane(ulo, 48)));
+      uhi = pk_max(pk_max(__builtin_amdgcn_readlane(uhi, 0), __builtin_amdgcn_readlane(uhi, 16)),
+                   pk_max(__builtin_amdgcn_readlane(uhi, 32), __builtin_amdgcn_readlane(uhi, 48)));
+      if (lane == 0) { swin[wv * 2] = ulo; swin[wv * 2 + 1] = uhi; }
+      CO_STAMP(1);
+    }
+    __syncthreads();
+
+    // ---- phase 1: the tile window, its rows dealt to the four waves; every fragment meets all four sub-blocks ----
+    {
+      CO_FRESH_LANE();
+      int tlo = 0x7fff7fff, thi = (int)0x80008000;  // the tile window = union of the sub-block windows (empty ones are neutral)
+#pragma unroll
+      for (int m = 0; m < CO_SB; m++) {
+        tlo = pk_min(tlo, swin[m * 2]);
+        thi = pk_max(thi, swin[m * 2 + 1]);
+      }
+      tlo = __builtin_amdgcn_readfirstlane(tlo); thi = __builtin_amdgcn_readfirstlane(thi);
+      int TX0 = pk_lo(tlo);
+      const int TY0 = pk_hi(tlo), TX1 = pk_lo(thi), TY1 = pk_hi(thi);
+      if (TX1 >= TX0 && TY1 >= TY0) {
+        TX0 &= ~1;  // pairs of positions start at even columns
+        // per sub-block m, this lane's pixel (m, lx): patch index of (row 0 of the map, column 4 lg of group 0) and the
+        // row / column ranges a store must fall in
+        int sb[CO_SB], sylo[CO_SB], sbh[CO_SB], sq0[CO_SB], swl[CO_SB];
+#pragma unroll
+        for (int m = 0; m < CO_SB; m++) {
+          const int4 pb = *reinterpret_cast<const int4*>(pbox + (m * 16 + lx) * 4);
+          const int xal = pb.x & ~1;
+          sylo[m] = pb.y;
+          sbh[m] = pb.w;                    // 0 = no patch: no row passes
+          swl[m] = pb.x + pb.z - 1 - xal;   // last patch column a pair may start at or before
+          sq0[m] = TX0 + 4 * lg - xal;      // patch column of this lane's first pair in group 0
+          sb[m] = (m * 16 + lx) * CO_PP - pb.y * CO_BOXP + sq0[m];
+        }
+        const int ngx = (TX1 - TX0 + 16) >> 4;
+        const int y0w = TY0 + wv;
+        const int nrow = y0w <= TY1 ? ((TY1 - y0w) >> 2) + 1 : 0;
+        const int nit = ngx * nrow;
+        // fragment addresses: uniform base per k-step (SGPR pair) + a 32-bit lane offset (host-checked: a level has
+        // < 2^31 elements).  Element strides of a position / a map row / a lane group / a k-step in the two storage forms:
+        const unsigned PSTR = p.f2_chunked ? EPL : C, YSTR = (unsigned)W2 * PSTR;
+        const unsigned GSTR = p.f2_chunked ? (unsigned)H2 * W2 * EPL : EPL;
+        const size_t KSTR = p.f2_chunked ? (size_t)4 * H2 * W2 * EPL : (size_t)CPS;
+        auto col_off = [&](int gx) {  // lane offset of row 0 in the column of groups starting at gx
+          int x = gx + lx;
+          x = x < W2 ? x : W2 - 1;  // padded positions re-read the last column; their results land in no box column that is read
+          return (unsigned)lg * GSTR + (unsigned)x * PSTR;
+        };
+        auto load_group = [&](frag (&dstf)[KS], unsigned coff, int y) __attribute__((always_inline)) {
+#ifdef LGU_CO_DIAG_SAMELOAD  // diagnostic builds only: every fragment load re-reads the window's first row (L1 hits)
+          const unsigned off = (coff + (unsigned)(y * 0 + TY0) * YSTR) * (unsigned)sizeof(T);
+#else
+          const unsigned off = (coff + (unsigned)y * YSTR) * (unsigned)sizeof(T);  // bytes
+#endif
+#pragma unroll
+          for (int s = 0; s < KS; s++)
+            dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
+        };
+        if (nit > 0) {
+          // The loop body is branch-free around its loads (a branch around a load makes hipcc wait for nearly every
+          // outstanding load at each use): the trip count is rounded up to a multiple of PF and the cursors stop at the
+          // last group, which the surplus steps load and store again.
+          frag bq[PF][KS];
+          int yl = y0w, gxl = TX0, li = 0;  // load cursor
+          unsigned cofl = col_off(TX0);
+          auto advance_load = [&]() __attribute__((always_inline)) {
+            if (li < nit - 1) {
+              li++;
+              yl += 4;
+              if (yl > TY1) { yl = y0w; gxl += 16; cofl = col_off(gxl); }
+            }
+          };
+#pragma unroll
+          for (int j = 0; j < PF; j++) {
+            load_group(bq[j], cofl, yl);
+            advance_load();
+          }
+          CO_STAMP(2);
+          // Every fragment is multiplied with all four sub-blocks (no per-sub-block window test: the matrix cores are
+          // not the bound); rows / columns outside a pixel's box are dropped by the store's range checks.
+          int y = y0w, gq = 0, ci = 0;  // compute cursor; gq = group column - TX0
+          for (int it = 0; it < nit; it += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+              cof32x4 d[CO_SB];
+#pragma unroll
+              for (int m = 0; m < CO_SB; m++) d[m] = cof32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int m = 0; m < CO_SB; m++) d[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[j][s], a[m][s], d[m], 0, 0, 0);
+              load_group(bq[j], cofl, yl);
+              advance_load();
+              const int yg = y * CO_BOXP + gq;  // scalar
+#pragma unroll
+              for (int m = 0; m < CO_SB; m++) {
+#ifdef LGU_CO_DIAG_NOSCATTER  // diagnostic builds only: results are consumed by one store per fragment instead of the patch stores
+                if (lane0 == 99) patch[m] = d[m][0] + d[m][1] + d[m][2] + d[m][3];
+                continue;
+#endif
+                if ((unsigned)(y - sylo[m]) < (unsigned)sbh[m]) {
+                  float* dst = patch + sb[m] + yg;
+                  const int qx = sq0[m] + gq;
+                  if ((unsigned)qx <= (unsigned)swl[m]) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0], d[m][1]);
+                  if ((unsigned)(qx + 2) <= (unsigned)swl[m]) *reinterpret_cast<float2*>(dst + 2) = make_float2(d[m][2], d[m][3]);
+                }
+              }
+              if (ci < nit - 1) {
+                ci++;
+                y += 4;
+                if (y > TY1) { y = y0w; gq += 16; }
+              }
+            }
+          }
+        }
+      }
+      CO_STAMP(3);
+    }
+    __syncthreads();
+
+    // ---- phase 2: sample the patches of the own sub-block ----
+    float res[4][TI];
+    {
+      CO_FRESH_LANE();
+      float2 o0[4][TI];
+      load_offsets(o0, lx, lg);
+      if (!zo && lx == CEN % 16) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap as phase 0 left it
+      }
+      int tix[TI], tiy[TI];
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const int t = lx + 16 * i;
+        tix[i] = t / RD;
+        tiy[i] = t - tix[i] * RD;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h1 = by * 4 + q, w1r = px0 + lg;
+        const bool pv = h1 < H1 && w1r < W1;
+        const int4 pb = *reinterpret_cast<const int4*>(pbox + (wv * 16 + q * 4 + lg) * 4);  // row-uniform
+        const int xal = pb.x & ~1, ylo = pb.y;
+        const bool has_patch = pb.w != 0, fallback = pb.z < 0;
+        const float* const Dp = patch + (wv * 16 + q * 4 + lg) * CO_PP;
+        const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
+        // zero-offset levels: one sample position per pixel — floor, fraction and the four weights once per pass
+        const float zfx = floorf(cx), zfy = floorf(cy);
+        const float zdx = cx - zfx, zdy = cy - zfy;
+        const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+          const bool tv = pv && lx + 16 * i < NT;
+          float fxs, fys, dx, dy;
+          if (zo) {
+            fxs = zfx; fys = zfy; dx = zdx; dy = zdy;
+          } else {
+            const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;
+            fxs = floorf(xs); fys = floorf(ys);
+            dx = xs - fxs; dy = ys - fys;  // :87-88
+          }
+          const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
+          const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
+          const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
+          const bool b11 = by0 && bx0, b21 = by0 && bx1, b12 = by1 && bx0, b22 = by1 && bx1;
+          float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+          if (tv && has_patch) {
+            // the four corners are read unconditionally and padded by selects: an in-bounds corner always lies inside the
+            // pixel's box; the others read whatever is there (inside the LDS allocation: CO_GUARD floats in front of the
+            // patches cover a top-left corner one row / column before the box, the tables behind them the overshoot)
+            const int idx = ((by0 || by1) && (bx0 || bx1)) ? (h2 - ylo) * CO_BOXP + (w2 - xal) : 0;
+            const float* D = Dp + idx;
+            const float d0 = D[0], d1 = D[1], d2 = D[CO_BOXP], d3 = D[CO_BOXP + 1];
+            q11 = b11 ? d0 : 0.f;
+            q21 = b21 ? d1 : 0.f;
+            q12 = b12 ? d2 : 0.f;
+            q22 = b22 ? d3 : 0.f;
+          } else if (tv && fallback) {
+            const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
+                                             (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0),
+                                             p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
+            q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+          }
+          if (zo) res[q][i] = q11 * zw11 + q21 * zw21 + q12 * zw12 + q22 * zw22;
+          else res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      CO_STAMP(4);
+    }
+
+    // ---- write-out: corr[b][n][ix][iy][h1][w1]; the wave's own patches become its [tap][pixel] transpose tile ----
+    {
+      CO_FRESH_LANE();
+      float* const outt = patch + wv * 16 * CO_PP;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+          if (lx + 16 * i < NT) outt[(lx + 16 * i) * CO_OUTP + q * 4 + lg] = res[q][i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float* const cb = p.corr + (((size_t)b * S + n) * p.Ltot + p.lvl0 + lvl) * NT * HW1;
+      for (int idx = lane; idx < NT * 4; idx += kWave) {
+        const int t = idx >> 2, q = idx & 3;
+        const int h1 = by * 4 + q, w1 = px0;
+        if (h1 >= H1 || w1 >= W1) continue;
+        const float4 v = *reinterpret_cast<const float4*>(outt + t * CO_OUTP + q * 4);
+        float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
+        if (p.vec_out) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          dst[0] = v.x;
+          if (w1 + 1 < W1) dst[1] = v.y;
+          if (w1 + 2 < W1) dst[2] = v.z;
+          if (w1 + 3 < W1) dst[3] = v.w;
+        }
+      }
+      CO_STAMP(5);
+    }
+  }
+}
+#undef CO_FRESH_LANE
+
+template <int R, int KS>
+static int launch_coop(CoParams p, hipStream_t st) {
+  auto kern = lowmem_coop_kernel<R, KS>;
+  const size_t lds = sizeof(float) * (size_t)CO_LDS_FLOATS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  p.tiles_x = (p.W1 + 15) / 16;
+  p.tiles_y = (p.H1 + 3) / 4;
+  const int tiles = p.tiles_x * p.tiles_y;
+  p.xcd_map = p.B >= 8 ? 1 : 0;
+  // level groups: every level with offsets is a unit of its own, a run of zero-offset levels is one unit
+  p.ngroups = 0;
+  for (int l = 0; l < p.L;) {
+    p.gl0[p.ngroups++] = l;
+    if (p.offset[l]) l++;
+    else while (l < p.L && !p.offset[l]) l++;
+  }
+  p.gl0[p.ngroups] = p.L;
+  for (int k = p.ngroups + 1; k <= CO_MAXL; k++) p.gl0[k] = p.L;
+  if (env_int("LGU_LOWMEM_COOP_FUSE", 0)) { p.ngroups = 1; for (int k = 1; k <= CO_MAXL; k++) p.gl0[k] = p.L; }  // A/B only: one unit serves all levels
+  const size_t nwg = (size_t)p.ngroups * (p.xcd_map ? (size_t)((p.B + 7) / 8) * 8 * tiles : (size_t)p.B * tiles);
+  if (nwg >= (1u << 31)) return -1;
+  p.vec_out = (p.W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.corr) & 15) == 0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)p.S), dim3(kWave * CO_SB), lds, st, p);
+  return launch_status();
+}
+
+// Serves half feature maps with C in {32, 64, 128} and radius 1..3; returns -1 otherwise (the caller then takes the
+// one-wave-per-block kernel of lowmem_mfma.hip).  LGU_LOWMEM_COOP=0 (debug / A-B only) disables it.
+int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
+                         const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int lbase,
+                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, hipStream_t st) {
+  if (env_int("LGU_LOWMEM_COOP", 1) == 0) return -1;
+  if (L < 1 || L > CO_MAXL || radius < 1 || radius > 3 || S > 65535) return -1;
+  uintptr_t al = reinterpret_cast<uintptr_t>(fmap1);
+  for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(fmap2[l]);
+  if ((al & 15) != 0) return -1;
+  if ((size_t)H1 * W1 * C >= (1u << 31)) return -1;
+  CoParams p = {};
+  p.fmap1 = static_cast<const _Float16*>(fmap1);
+  for (int l = 0; l < L; l++) {
+    if ((size_t)H2[l] * W2[l] * C >= (1u << 31) || H2[l] > 32767 || W2[l] > 32767) return -1;
+    p.fmap2[l] = static_cast<const _Float16*>(fmap2[l]);
+    p.offset[l] = offset[l];
+    p.H2[l] = H2[l]; p.W2[l] = W2[l];
+  }
+  p.coords = coords; p.corr = corr;
+  p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
+  p.lbase = lbase; p.lvl0 = lvl0; p.Ltot = Ltot; p.f2_chunked = f2_chunked; p.ii = ii; p.jj = jj;
+#define LGU_CO_CASE(RV, KSV) \
+  if (radius == RV && C == 32 * KSV) return launch_coop<RV, KSV>(p, st);
+  LGU_CO_CASE(3, 4) LGU_CO_CASE(1, 4) LGU_CO_CASE(2, 4)
+  LGU_CO_CASE(3, 2) LGU_CO_CASE(1, 2) LGU_CO_CASE(2, 2)
+  LGU_CO_CASE(3, 1) LGU_CO_CASE(1, 1) LGU_CO_CASE(2, 1)
+#undef LGU_CO_CASE
+  return -1;
+}
+
+}  // namespace lgu
+
+#ifdef LGU_MM_STAMPS
+// Diagnostic build only (tools/diag/run_co_stamps.py): never part of liblgu_corr.so.
+extern "C" {
+int lgu_co_diag_set_stamps(void* q) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(lgu::g_co_stamps), &q, sizeof(q)); }
+int lgu_co_diag_pyramid(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
+                        const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int chunked) {
+  return lgu::lowmem_coop_dispatch(fmap1, fmap2, offset, coords, corr, H2, W2, L, B, S, H1, W1, C, radius, 0, 0, L, chunked,
+                                   nullptr, nullptr, nullptr);
+}
+}
+#endif

@@ -576,8 +576,18 @@ static int launch_mfma(const MmParams& p, hipStream_t st) {
   return LGU_OK;
 }
 
+// lowmem_coop.hip: four waves share the swept windows, all levels in one wave life (half maps, C <= 128)
+int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
+                         const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int lbase,
+                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, hipStream_t st);
+
 template <typename T>
 static int mfma_dispatch(const MmParams& p, int C, int radius, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const int rc = lowmem_coop_dispatch(p.fmap1, p.fmap2, p.offset, p.coords, p.corr, p.H2, p.W2, p.L, p.B, p.S, p.H1, p.W1, C,
+                                        radius, p.lbase, p.lvl0, p.Ltot, p.f2_chunked, p.ii, p.jj, st);
+    if (rc >= 0) return rc;
+  }
   uintptr_t al = reinterpret_cast<uintptr_t>(p.fmap1);
   for (int l = 0; l < p.L; l++) al |= reinterpret_cast<uintptr_t>(p.fmap2[l]);
   if (radius < 1 || radius > 3 || (al & 15) != 0 || p.S > 65535) return -1;
