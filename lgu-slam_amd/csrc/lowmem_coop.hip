@@ -32,14 +32,16 @@ namespace lgu {
 typedef _Float16 cohalf8 __attribute__((ext_vector_type(8)));
 typedef float cof32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CO_SB = 4;                       // 4 x 4 sub-blocks (= waves) per workgroup
+constexpr int CO_SB = 2;                       // 4 x 4 sub-blocks per workgroup (tile = 4 rows x 8 columns of pixels)
+constexpr int CO_NW = 4;                       // waves per workgroup: two per sub-block in the box / sampling phases
+constexpr int CO_QP = 16 * CO_SB / (4 * CO_NW);  // passes (pixel rows) per wave = 2
 constexpr int CO_NPX = 16 * CO_SB;             // pixels per workgroup
 constexpr int CO_BOXP = 18;                    // patch row pitch: 16 columns + the even-alignment slack, pairs 8-byte aligned
 constexpr int CO_PP = 16 * CO_BOXP + 2;        // floats per patch (+2: consecutive pixels start 8 banks apart)
 constexpr int CO_GUARD = 20;                   // floats in front of the patches (>= CO_BOXP + 1): see the sampling phase
-constexpr int CO_OUTP = 20;                    // output transpose pitch
+constexpr int CO_OUTP = 4 * CO_QP + 4;          // output transpose pitch
 constexpr int CO_MAXL = 4;
-constexpr int CO_LDS_FLOATS = CO_GUARD + CO_NPX * CO_PP + CO_NPX * 4 + 2 * CO_SB + 8;
+constexpr int CO_LDS_FLOATS = CO_GUARD + CO_NPX * CO_PP + CO_NPX * 4 + 2 * CO_NW + 8;
 
 struct CoParams {
   const _Float16* fmap1;
@@ -51,7 +53,11 @@ struct CoParams {
   int L, B, S, H1, W1, tiles_x, tiles_y, xcd_map, vec_out;
   int lbase, lvl0, Ltot;
   int f2_chunked;
-  int ngroups, gl0[CO_MAXL + 1];  // work units = (level group, edge, tile): group k serves levels gl0[k] .. gl0[k + 1] - 1
+  // Work units.  The first n_fused workgroups serve ALL levels of their (edge, tile) in one wave life; the remaining
+  // n_split (edge, tile) items are served level group by level group (group k = levels gl0[k] .. gl0[k + 1] - 1), groups in
+  // launch order: n_fused is a whole number of rounds over the device's workgroup slots, and the short units fill the
+  // last, partial round (launch_coop).
+  int n_fused, n_split, ngroups, gl0[CO_MAXL + 1];
   const long long* ii;
   const long long* jj;
 };
@@ -95,7 +101,7 @@ __device__ __forceinline__ int co_row_pk_reduce(int v) {
 __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 #define CO_STAMP(i)                                                                                                        \
   do {                                                                                                                     \
-    if (lane == 0 && blockIdx.y == 0) g_co_stamps[((size_t)blockIdx.x * CO_SB + wv) * 32 + lvl * 8 + (i)] = wall_clock64(); \
+    if (lane == 0 && blockIdx.y == 0) g_co_stamps[((size_t)blockIdx.x * CO_NW + wv) * 32 + lvl * 8 + (i)] = wall_clock64(); \
   } while (0)
 #else
 #define CO_STAMP(i)
@@ -113,32 +119,37 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
   asm volatile("" : "+v"(lane));        \
   const int lx = lane & 15, lg = lane >> 4;
 
-template <int R, int KS>
-__global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoParams p) {
+// PRE: a level's offsets are requested one step ahead of their use (16 more registers: compiled for 3 waves per SIMD
+// instead of 4).
+template <int R, int KS, bool PRE>
+__global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(const CoParams p) {
+  constexpr bool CO_PREFETCH = PRE;
   typedef _Float16 T;
   typedef cohalf8 frag;
   constexpr int CPS = 32, EPL = 8;
   constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
   constexpr int TI = (NT + 15) / 16;
   constexpr int CEN = R * RD + R;
-  constexpr int PF = 3;  // position fragments in flight per wave
+  constexpr int PF = 2;  // position fragments in flight per wave
   extern __shared__ float smem[];
   float* const patch = smem + CO_GUARD;                                   // [CO_NPX][CO_PP]
   int* const pbox = reinterpret_cast<int*>(patch + CO_NPX * CO_PP);       // [CO_NPX][xlo, ylo, bw, bh]
-  int* const swin = pbox + CO_NPX * 4;                                    // [CO_SB][lo, hi] packed
+  int* const swin = pbox + CO_NPX * 4;                                    // [CO_NW][lo, hi] packed: window of each wave's pixels
   const int lane0 = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: scalar
   const int B = p.B, S = p.S, H1 = p.H1, W1 = p.W1;
 
-  // ---- workgroup -> (level group, edge, tile): groups in launch order, so the long units (levels with offsets) start
-  // first and the short ones fill the tail; the hardware's in-order dispatch to free slots does the balancing ----
+  // ---- workgroup -> (levels, edge, tile) ----
   int b, blk;
   const int tiles = p.tiles_x * p.tiles_y;
-  const int per_group = (p.xcd_map ? ((B + 7) >> 3) * 8 : B) * tiles;
-  const int grp = (int)blockIdx.x / per_group, item = (int)blockIdx.x - grp * per_group;
-  int lv0 = p.gl0[0], lv1 = p.gl0[1];
+  int item = (int)blockIdx.x, lv0 = 0, lv1 = p.L;
+  if (item >= p.n_fused) {
+    const int u = item - p.n_fused, grp = u / p.n_split;
+    item = p.n_fused + (u - grp * p.n_split);
+    lv0 = p.gl0[0]; lv1 = p.gl0[1];
 #pragma unroll
-  for (int k = 1; k < CO_MAXL; k++)
-    if (grp == k) { lv0 = p.gl0[k]; lv1 = p.gl0[k + 1]; }
+    for (int k = 1; k < CO_MAXL; k++)
+      if (grp == k) { lv0 = p.gl0[k]; lv1 = p.gl0[k + 1]; }
+  }
   if (p.xcd_map) {
     const int xcd = item & 7, slot = item >> 3;
     b = (slot / tiles) * 8 + xcd;
@@ -150,54 +161,84 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
   }
   const int n = blockIdx.y;
   const int by = blk / p.tiles_x, bx = blk % p.tiles_x;
-  const int px0 = bx * 16 + wv * 4;  // first pixel column of this wave's sub-block
+  const int msb = wv >> 1, qr0 = (wv & 1) * CO_QP;  // this wave's sub-block and the first of its pixel rows in it
+  const int px0 = bx * (4 * CO_SB) + msb * 4;  // first pixel column of this wave's sub-block
   const size_t HW1 = (size_t)H1 * W1;
   const size_t f1i = p.ii ? (size_t)p.ii[b] : (size_t)b, f2i = p.jj ? (size_t)p.jj[b] : (size_t)b;
   const T* const F1 = p.fmap1 + f1i * HW1 * C;
   const float2* const cbase = reinterpret_cast<const float2*>(p.coords) + ((size_t)b * S + n) * HW1;
 
-  // ---- once per wave life: coords of the own sub-block, fmap1 fragments of the whole tile ----
-  float2 cv0[4];
+  // Levels are served coarse to fine.  A level's offsets (16 registers) are requested one step ahead of their use: right
+  // after the sampling of the level before it, so they travel during that level's write-out and the barrier (held across
+  // a whole zero-offset level they cost 16 registers where the kernel has none to spare).
+  auto level_offsets = [&](int l) -> float* {  // workgroup-uniform; reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
+    float* o = p.offset[0];
+#pragma unroll
+    for (int k = 1; k < CO_MAXL; k++)
+      if (l == k) o = p.offset[k];
+    return o ? o + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+  };
+  float2 o0[CO_QP][TI];
+  auto request_offsets = [&](int l) __attribute__((always_inline)) {  // offsets of level l, if it is served here and has any
+    if (l < lv0) return;
+    const float* const ob = level_offsets(l);
+    if (!ob) return;
+    CO_FRESH_LANE();
+#pragma unroll
+    for (int q = 0; q < CO_QP; q++) {
+      const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
+      const bool pv = h1 < H1 && w1r < W1;
+      const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const int t = lx + 16 * i;
+        o0[q][i] = make_float2(0.f, 0.f);
+        if (pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(ob + pix * NT * 2)[t];
+      }
+    }
+  };
+
+  // ---- once per wave life: coords of the own pixels, the first offsets, fmap1 fragments of the whole tile (requested
+  // last: loads return in order, and the boxes must not wait for these 8 KB) ----
+  float2 cv0[CO_QP];
   frag a[CO_SB][KS];
+#pragma unroll
+  for (int q = 0; q < CO_QP; q++)
+#pragma unroll
+    for (int i = 0; i < TI; i++) o0[q][i] = make_float2(0.f, 0.f);
   {
     CO_FRESH_LANE();
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int h1 = by * 4 + q, w1r = px0 + lg;
+    for (int q = 0; q < CO_QP; q++) {
+      const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
       const bool pv = h1 < H1 && w1r < W1;
       cv0[q] = cbase[pv ? (size_t)h1 * W1 + w1r : 0];
     }
   }
+  if (CO_PREFETCH) request_offsets(lv1 - 1);
+  {
+    CO_FRESH_LANE();
+#pragma unroll
+    for (int m = 0; m < CO_SB; m++) {
+      int h1 = by * 4 + (lx >> 2), w1 = bx * (4 * CO_SB) + m * 4 + (lx & 3);
+      h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
+      const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
+#pragma unroll
+      for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
+    }
+  }
 
-  for (int lvl = lv0; lvl < lv1; lvl++) {
+  for (int lvl = lv1 - 1; lvl >= lv0; lvl--) {
     const T* fmap2 = p.fmap2[0];
-    float* offset = p.offset[0];
     int H2 = p.H2[0], W2 = p.W2[0];
 #pragma unroll
     for (int l = 1; l < CO_MAXL; l++)
-      if (lvl == l) { fmap2 = p.fmap2[l]; offset = p.offset[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
+      if (lvl == l) { fmap2 = p.fmap2[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
     const float cscale = __builtin_ldexpf(1.0f, -(p.lbase + lvl));
     const T* const F2 = fmap2 + f2i * H2 * W2 * C;
-    // reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83); null = zero offsets
-    float* const obase = offset ? offset + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+    float* const obase = level_offsets(lvl);  // null = zero offsets
     const bool zo = obase == nullptr;  // workgroup-uniform
-
-    // offsets of the own sub-block: loaded twice per level (for the boxes, and again behind the sweep for the sampling —
-    // the second read hits L2) instead of holding 32 registers across the sweep
-    auto load_offsets = [&](float2 (&o0)[4][TI], int lx, int lg) __attribute__((always_inline)) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int h1 = by * 4 + q, w1r = px0 + lg;
-        const bool pv = h1 < H1 && w1r < W1;
-        const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
-#pragma unroll
-        for (int i = 0; i < TI; i++) {
-          const int t = lx + 16 * i;
-          o0[q][i] = make_float2(0.f, 0.f);
-          if (!zo && pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(obase + pix * NT * 2)[t];
-        }
-      }
-    };
+    if (!CO_PREFETCH) request_offsets(lvl);
 
     // ---- phase 0: sample positions and tap boxes of the own sub-block ----
     {
@@ -210,22 +251,10 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
         tix[i] = t / RD;
         tiy[i] = t - tix[i] * RD;
       }
-      float2 o0[4][TI];
-      load_offsets(o0, lx, lg);
-      if (lvl == lv0) {  // fmap1 fragments of the whole tile, requested behind the offsets (loads return in order: the boxes must not wait for these 16 KB)
-#pragma unroll
-        for (int m = 0; m < CO_SB; m++) {
-          int h1 = by * 4 + (lx >> 2), w1 = bx * 16 + m * 4 + (lx & 3);
-          h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
-          const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
-#pragma unroll
-          for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
-        }
-      }
       if (!zo) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int h1 = by * 4 + q, w1r = px0 + lg;
+        for (int q = 0; q < CO_QP; q++) {
+          const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
           constexpr int ci = CEN / 16;
           if (lx == CEN % 16 && h1 < H1 && w1r < W1) {
             if ((__builtin_bit_cast(unsigned, o0[q][ci].x) | __builtin_bit_cast(unsigned, o0[q][ci].y)) != 0u)
@@ -236,8 +265,8 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
       }
       int ulo = 0x7fff7fff, uhi = (int)0x80008000;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int h1 = by * 4 + q, w1r = px0 + lg;
+      for (int q = 0; q < CO_QP; q++) {
+        const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
         const bool pv = h1 < H1 && w1r < W1;
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
         int lo = 0x7fff7fff, hi = (int)0x80008000;
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
         ulo = boxed ? pk_min(ulo, lo) : ulo;
         uhi = boxed ? pk_max(uhi, hi) : uhi;
         if (lx == 0) {  // box table: (bw, bh) of a patch; (-1, 0) = box larger than a patch (per-tap fallback); (0, 0) = nothing to sample
-          int* pb = pbox + (wv * 16 + q * 4 + lg) * 4;
+          int* pb = pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4;
           pb[0] = xlo; pb[1] = ylo;
           pb[2] = boxed ? xhi - xlo + 1 : (any ? -1 : 0);
           pb[3] = boxed ? yhi - ylo + 1 : 0;
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
       CO_FRESH_LANE();
       int tlo = 0x7fff7fff, thi = (int)0x80008000;  // the tile window = union of the sub-block windows (empty ones are neutral)
 #pragma unroll
-      for (int m = 0; m < CO_SB; m++) {
+      for (int m = 0; m < CO_NW; m++) {
         tlo = pk_min(tlo, swin[m * 2]);
         thi = pk_max(thi, swin[m * 2 + 1]);
       }
@@ -311,7 +340,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
         }
         const int ngx = (TX1 - TX0 + 16) >> 4;
         const int y0w = TY0 + wv;
-        const int nrow = y0w <= TY1 ? ((TY1 - y0w) >> 2) + 1 : 0;
+        const int nrow = y0w <= TY1 ? ((TY1 - y0w) / CO_NW) + 1 : 0;
         const int nit = ngx * nrow;
         // fragment addresses: uniform base per k-step (SGPR pair) + a 32-bit lane offset (host-checked: a level has
         // < 2^31 elements).  Element strides of a position / a map row / a lane group / a k-step in the two storage forms:
@@ -324,11 +353,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
           return (unsigned)lg * GSTR + (unsigned)x * PSTR;
         };
         auto load_group = [&](frag (&dstf)[KS], unsigned coff, int y) __attribute__((always_inline)) {
-#ifdef LGU_CO_DIAG_SAMELOAD  // diagnostic builds only: every fragment load re-reads the window's first row (L1 hits)
-          const unsigned off = (coff + (unsigned)(y * 0 + TY0) * YSTR) * (unsigned)sizeof(T);
-#else
           const unsigned off = (coff + (unsigned)y * YSTR) * (unsigned)sizeof(T);  // bytes
-#endif
 #pragma unroll
           for (int s = 0; s < KS; s++)
             dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
@@ -343,7 +368,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
           auto advance_load = [&]() __attribute__((always_inline)) {
             if (li < nit - 1) {
               li++;
-              yl += 4;
+              yl += CO_NW;
               if (yl > TY1) { yl = y0w; gxl += 16; cofl = col_off(gxl); }
             }
           };
@@ -353,8 +378,8 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
             advance_load();
           }
           CO_STAMP(2);
-          // Every fragment is multiplied with all four sub-blocks (no per-sub-block window test: the matrix cores are
-          // not the bound); rows / columns outside a pixel's box are dropped by the store's range checks.
+          // Every fragment is multiplied with both sub-blocks; rows / columns outside a pixel's box are dropped by the
+          // store's range checks.
           int y = y0w, gq = 0, ci = 0;  // compute cursor; gq = group column - TX0
           for (int it = 0; it < nit; it += PF) {
 #pragma unroll
@@ -371,10 +396,6 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
               const int yg = y * CO_BOXP + gq;  // scalar
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) {
-#ifdef LGU_CO_DIAG_NOSCATTER  // diagnostic builds only: results are consumed by one store per fragment instead of the patch stores
-                if (lane0 == 99) patch[m] = d[m][0] + d[m][1] + d[m][2] + d[m][3];
-                continue;
-#endif
                 if ((unsigned)(y - sylo[m]) < (unsigned)sbh[m]) {
                   float* dst = patch + sb[m] + yg;
                   const int qx = sq0[m] + gq;
@@ -384,7 +405,7 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
               }
               if (ci < nit - 1) {
                 ci++;
-                y += 4;
+                y += CO_NW;
                 if (y > TY1) { y = y0w; gq += 16; }
               }
             }
@@ -396,15 +417,9 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
     __syncthreads();
 
     // ---- phase 2: sample the patches of the own sub-block ----
-    float res[4][TI];
+    float res[CO_QP][TI];
     {
       CO_FRESH_LANE();
-      float2 o0[4][TI];
-      load_offsets(o0, lx, lg);
-      if (!zo && lx == CEN % 16) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap as phase 0 left it
-      }
       int tix[TI], tiy[TI];
 #pragma unroll
       for (int i = 0; i < TI; i++) {
@@ -413,13 +428,13 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
         tiy[i] = t - tix[i] * RD;
       }
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int h1 = by * 4 + q, w1r = px0 + lg;
+      for (int q = 0; q < CO_QP; q++) {
+        const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
         const bool pv = h1 < H1 && w1r < W1;
-        const int4 pb = *reinterpret_cast<const int4*>(pbox + (wv * 16 + q * 4 + lg) * 4);  // row-uniform
+        const int4 pb = *reinterpret_cast<const int4*>(pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4);  // row-uniform
         const int xal = pb.x & ~1, ylo = pb.y;
         const bool has_patch = pb.w != 0, fallback = pb.z < 0;
-        const float* const Dp = patch + (wv * 16 + q * 4 + lg) * CO_PP;
+        const float* const Dp = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP;
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
         // zero-offset levels: one sample position per pixel — floor, fraction and the four weights once per pass
         const float zfx = floorf(cx), zfy = floorf(cy);
@@ -466,13 +481,14 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
       __builtin_amdgcn_wave_barrier();
       CO_STAMP(4);
     }
+    if (CO_PREFETCH) request_offsets(lvl - 1);  // this level's offsets are consumed: the next level's travel during the write-out
 
     // ---- write-out: corr[b][n][ix][iy][h1][w1]; the wave's own patches become its [tap][pixel] transpose tile ----
     {
       CO_FRESH_LANE();
-      float* const outt = patch + wv * 16 * CO_PP;
+      float* const outt = patch + (msb * 16 + qr0 * 4) * CO_PP;  // the patches of the wave's own pixels
 #pragma unroll
-      for (int q = 0; q < 4; q++)
+      for (int q = 0; q < CO_QP; q++)
 #pragma unroll
         for (int i = 0; i < TI; i++)
           if (lx + 16 * i < NT) outt[(lx + 16 * i) * CO_OUTP + q * 4 + lg] = res[q][i];
@@ -480,9 +496,9 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float* const cb = p.corr + (((size_t)b * S + n) * p.Ltot + p.lvl0 + lvl) * NT * HW1;
-      for (int idx = lane; idx < NT * 4; idx += kWave) {
-        const int t = idx >> 2, q = idx & 3;
-        const int h1 = by * 4 + q, w1 = px0;
+      for (int idx = lane; idx < NT * CO_QP; idx += kWave) {
+        const int t = idx / CO_QP, q = idx - t * CO_QP;
+        const int h1 = by * 4 + qr0 + q, w1 = px0;
         if (h1 >= H1 || w1 >= W1) continue;
         const float4 v = *reinterpret_cast<const float4*>(outt + t * CO_OUTP + q * 4);
         float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
@@ -501,33 +517,53 @@ __global__ __launch_bounds__(kWave* CO_SB, 2) void lowmem_coop_kernel(const CoPa
 }
 #undef CO_FRESH_LANE
 
-template <int R, int KS>
+template <int R, int KS, bool PRE>
 static int launch_coop(CoParams p, hipStream_t st) {
-  auto kern = lowmem_coop_kernel<R, KS>;
+  auto kern = lowmem_coop_kernel<R, KS, PRE>;
+  constexpr int CO_WPS = PRE ? 3 : 4;
   const size_t lds = sizeof(float) * (size_t)CO_LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  p.tiles_x = (p.W1 + 15) / 16;
+  p.tiles_x = (p.W1 + 4 * CO_SB - 1) / (4 * CO_SB);
   p.tiles_y = (p.H1 + 3) / 4;
   const int tiles = p.tiles_x * p.tiles_y;
   p.xcd_map = p.B >= 8 ? 1 : 0;
-  // level groups: every level with offsets is a unit of its own, a run of zero-offset levels is one unit
+  // level groups of the split items: every level with offsets is a unit of its own, a run of zero-offset levels is one
   p.ngroups = 0;
   for (int l = 0; l < p.L;) {
     p.gl0[p.ngroups++] = l;
     if (p.offset[l]) l++;
     else while (l < p.L && !p.offset[l]) l++;
   }
-  p.gl0[p.ngroups] = p.L;
-  for (int k = p.ngroups + 1; k <= CO_MAXL; k++) p.gl0[k] = p.L;
-  if (env_int("LGU_LOWMEM_COOP_FUSE", 0)) { p.ngroups = 1; for (int k = 1; k <= CO_MAXL; k++) p.gl0[k] = p.L; }  // A/B only: one unit serves all levels
-  const size_t nwg = (size_t)p.ngroups * (p.xcd_map ? (size_t)((p.B + 7) / 8) * 8 * tiles : (size_t)p.B * tiles);
+  for (int k = p.ngroups; k <= CO_MAXL; k++) p.gl0[k] = p.L;
+  // Fused workgroups in whole rounds over the device's slots (4 resident workgroups per CU), the remainder split by
+  // level group so that the last round is made of short units: a call of 2.3 rounds costs ~2.4 instead of 3.
+  // LGU_LOWMEM_COOP_SPLIT (debug / A-B only): 0 = all fused, 1 = all split, default = the rule above.
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+    slots = CO_WPS * cus;
+  }
+  const size_t items = p.xcd_map ? (size_t)((p.B + 7) / 8) * 8 * tiles : (size_t)p.B * tiles;
+  if (items >= (1u << 30)) return -1;
+  const int mode = env_int("LGU_LOWMEM_COOP_SPLIT", -1);
+  size_t fused = items;
+  if (p.ngroups > 1) {
+    if (mode == 1) fused = 0;
+    else if (mode != 0 && items > (size_t)slots && items < (size_t)8 * slots) fused = items / slots * slots;
+  }
+  p.n_fused = (int)fused;
+  p.n_split = (int)(items - fused);
+  if (p.n_split == 0) p.n_split = 1;  // never divided by when unused
+  const size_t nwg = fused + (items - fused) * p.ngroups;
   if (nwg >= (1u << 31)) return -1;
   p.vec_out = (p.W1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.corr) & 15) == 0);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)p.S), dim3(kWave * CO_SB), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)p.S), dim3(kWave * CO_NW), lds, st, p);
   return launch_status();
 }
 
@@ -553,8 +589,9 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   p.coords = coords; p.corr = corr;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.lvl0 = lvl0; p.Ltot = Ltot; p.f2_chunked = f2_chunked; p.ii = ii; p.jj = jj;
+  const bool pre = env_int("LGU_LOWMEM_COOP_PRE", 0) != 0;
 #define LGU_CO_CASE(RV, KSV) \
-  if (radius == RV && C == 32 * KSV) return launch_coop<RV, KSV>(p, st);
+  if (radius == RV && C == 32 * KSV) return pre ? launch_coop<RV, KSV, true>(p, st) : launch_coop<RV, KSV, false>(p, st);
   LGU_CO_CASE(3, 4) LGU_CO_CASE(1, 4) LGU_CO_CASE(2, 4)
   LGU_CO_CASE(3, 2) LGU_CO_CASE(1, 2) LGU_CO_CASE(2, 2)
   LGU_CO_CASE(3, 1) LGU_CO_CASE(1, 1) LGU_CO_CASE(2, 1)

@@ -43,7 +43,7 @@ OF = (vp * nl)(*[offs[l].data_ptr() if offs[l] is not None else None for l in le
 H2 = (ctypes.c_int * nl)(*[H >> l for l in levels])
 W2 = (ctypes.c_int * nl)(*[W >> l for l in levels])
 corr = torch.empty(B, 1, nl * 49, H, W, device=dev)
-nwg = 4 * ((B + 7) // 8) * 8 * ((W + 15) // 16) * ((H + 3) // 4)  # up to one work unit per level
+nwg = 4 * ((B + 7) // 8) * 8 * ((W + 7) // 8) * ((H + 3) // 4)  # up to one work unit per level
 stamps = torch.zeros(nwg, 4, 32, dtype=torch.int64, device=dev)
 lib.lgu_co_diag_set_stamps(vp(stamps.data_ptr()))
 for it in range(3):
