@@ -240,17 +240,14 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
     const bool zo = obase == nullptr;  // workgroup-uniform
     if (!CO_PREFETCH) request_offsets(lvl);
 
-    // ---- phase 0: sample positions and tap boxes of the own sub-block ----
+    // ---- phase 0: tap boxes of the wave's own pixels ----
+    // A pixel's box is the extent of ALL its taps' corners, NOT clipped to the map (<= 16 x 16 for |offset| < 4, whatever
+    // the coords): the patch then holds every corner of every tap, the ones outside the map as zeros (patches of pixels
+    // whose box crosses the border are zero-filled here, before the sweep stores the in-map entries), and the sampling
+    // phase needs neither range checks nor selects for the reference's per-corner zero padding (:102-117).
     {
       CO_FRESH_LANE();
       CO_STAMP(0);
-      int tix[TI], tiy[TI];
-#pragma unroll
-      for (int i = 0; i < TI; i++) {
-        const int t = lx + 16 * i;
-        tix[i] = t / RD;
-        tiy[i] = t - tix[i] * RD;
-      }
       if (!zo) {  // reference side effect (:80-81): offset[centre] = 0, stored only where the bits are not +0 already
 #pragma unroll
         for (int q = 0; q < CO_QP; q++) {
@@ -263,44 +260,61 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
           }
         }
       }
+      float tfx[TI], tfy[TI];  // tap index - R as floats (lanes past the last tap repeat it: neutral for the extent)
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        int t = lx + 16 * i;
+        t = t < NT ? t : NT - 1;
+        const int ix = t / RD;
+        tfx[i] = (float)(ix - R);
+        tfy[i] = (float)(t - ix * RD - R);
+      }
       int ulo = 0x7fff7fff, uhi = (int)0x80008000;
+      bool border = false;
 #pragma unroll
       for (int q = 0; q < CO_QP; q++) {
         const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
         const bool pv = h1 < H1 && w1r < W1;
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
-        int lo = 0x7fff7fff, hi = (int)0x80008000;
+        int lo, hi;  // packed (x, y) of the first / last column and row the taps' top-left corners reach
         if (zo) {
-          // taps i, j = -R..R at floor(c) + (i, j), corners one further: the lattice [f - R, f + R + 1]^2 clipped to the map
           const int fx = (int)floorf(cx), fy = (int)floorf(cy);
-          const int xa = fx - R > 0 ? fx - R : 0, xb = fx + R + 1 < W2 ? fx + R + 1 : W2 - 1;
-          const int ya = fy - R > 0 ? fy - R : 0, yb = fy + R + 1 < H2 ? fy + R + 1 : H2 - 1;
-          if (pv && xa <= xb && ya <= yb) { lo = pk16(xa, ya); hi = pk16(xb, yb); }
+          lo = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(fx - R, fy - R));
+          hi = __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(fx + R, fy + R));
         } else {
+          float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
 #pragma unroll
           for (int i = 0; i < TI; i++) {
-            const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;  // :82-83
-            const int w2 = (int)floorf(xs) - R + tix[i], h2 = (int)floorf(ys) - R + tiy[i];
-            const int xa = w2 > 0 ? w2 : 0, xb = w2 + 1 < W2 ? w2 + 1 : W2 - 1;
-            const int ya = h2 > 0 ? h2 : 0, yb = h2 + 1 < H2 ? h2 + 1 : H2 - 1;
-            const bool part = pv && lx + 16 * i < NT && xa <= xb && ya <= yb;  // at least one corner in bounds
-            lo = part ? pk_min(lo, pk16(xa, ya)) : lo;
-            hi = part ? pk_max(hi, pk16(xb, yb)) : hi;
+            const float wx = floorf(cx + o0[q][i].x) + tfx[i], wy = floorf(cy + o0[q][i].y) + tfy[i];  // :82-83, exact integers
+            x0 = fminf(x0, wx); x1 = fmaxf(x1, wx);
+            y0 = fminf(y0, wy); y1 = fmaxf(y1, wy);
           }
-          lo = co_row_pk_reduce<true>(lo);
-          hi = co_row_pk_reduce<false>(hi);
+          // saturating conversion: absurd or non-finite coords give a box that fails the size test below
+          lo = co_row_pk_reduce<true>(__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16((int)x0, (int)y0)));
+          hi = co_row_pk_reduce<false>(__builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16((int)x1, (int)y1)));
         }
-        const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi), yhi = pk_hi(hi);
-        const bool any = xhi >= xlo && yhi >= ylo;
+        const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi) + 1, yhi = pk_hi(hi) + 1;  // + 1: the right / bottom corners
+        const bool any = pv && xhi > xlo && yhi > ylo;
         const bool boxed = any && xhi - xlo < 16 && yhi - ylo < 16;
-        ulo = boxed ? pk_min(ulo, lo) : ulo;
-        uhi = boxed ? pk_max(uhi, hi) : uhi;
+        // what the sweep has to visit: the box clipped to the map
+        const int cx0 = xlo > 0 ? xlo : 0, cy0 = ylo > 0 ? ylo : 0, cx1 = xhi < W2 ? xhi : W2 - 1, cy1 = yhi < H2 ? yhi : H2 - 1;
+        const bool inmap = boxed && cx0 <= cx1 && cy0 <= cy1;
+        ulo = inmap ? pk_min(ulo, pk16(cx0, cy0)) : ulo;
+        uhi = inmap ? pk_max(uhi, pk16(cx1, cy1)) : uhi;
+        border = border || (boxed && (xlo < 0 || ylo < 0 || xhi >= W2 || yhi >= H2));
         if (lx == 0) {  // box table: (bw, bh) of a patch; (-1, 0) = box larger than a patch (per-tap fallback); (0, 0) = nothing to sample
           int* pb = pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4;
           pb[0] = xlo; pb[1] = ylo;
           pb[2] = boxed ? xhi - xlo + 1 : (any ? -1 : 0);
           pb[3] = boxed ? yhi - ylo + 1 : 0;
         }
+      }
+      if (__builtin_amdgcn_ballot_w64(border) != 0) {  // wave-uniform: zero the patches of the wave's own pixels
+        float4* z = reinterpret_cast<float4*>(patch + (msb * 16 + qr0 * 4) * CO_PP);
+        constexpr int NZ = 4 * CO_QP * CO_PP / 4;  // float4s
+#pragma unroll
+        for (int k = 0; k < (NZ + kWave - 1) / kWave; k++)
+          if (k * kWave + lane < NZ) z[k * kWave + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       ulo = pk_min(pk_min(__builtin_amdgcn_readlane(ulo, 0), __builtin_amdgcn_readlane(ulo, 16)),
                    pk_min(__builtin_amdgcn_readlane(ulo, 32), __builtin_amdgcn_readlane(ulo, 48)));
@@ -325,9 +339,10 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
       const int TY0 = pk_hi(tlo), TX1 = pk_lo(thi), TY1 = pk_hi(thi);
       if (TX1 >= TX0 && TY1 >= TY0) {
         TX0 &= ~1;  // pairs of positions start at even columns
-        // per sub-block m, this lane's pixel (m, lx): patch index of (row 0 of the map, column 4 lg of group 0) and the
-        // row / column ranges a store must fall in
-        int sb[CO_SB], sylo[CO_SB], sbh[CO_SB], sq0[CO_SB], swl[CO_SB];
+        // per sub-block m, this lane's pixel (m, lx): byte address in LDS of the patch entry of (row 0 of the map, column
+        // 4 lg of group 0), and the row / column ranges a store must fall in
+        float* sbp[CO_SB];
+        int sylo[CO_SB], sbh[CO_SB], sq0[CO_SB], swl[CO_SB];
 #pragma unroll
         for (int m = 0; m < CO_SB; m++) {
           const int4 pb = *reinterpret_cast<const int4*>(pbox + (m * 16 + lx) * 4);
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
           sbh[m] = pb.w;                    // 0 = no patch: no row passes
           swl[m] = pb.x + pb.z - 1 - xal;   // last patch column a pair may start at or before
           sq0[m] = TX0 + 4 * lg - xal;      // patch column of this lane's first pair in group 0
-          sb[m] = (m * 16 + lx) * CO_PP - pb.y * CO_BOXP + sq0[m];
+          sbp[m] = patch + (m * 16 + lx) * CO_PP - pb.y * CO_BOXP + sq0[m];
         }
         const int ngx = (TX1 - TX0 + 16) >> 4;
         const int y0w = TY0 + wv;
@@ -347,40 +362,44 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
         const unsigned PSTR = p.f2_chunked ? EPL : C, YSTR = (unsigned)W2 * PSTR;
         const unsigned GSTR = p.f2_chunked ? (unsigned)H2 * W2 * EPL : EPL;
         const size_t KSTR = p.f2_chunked ? (size_t)4 * H2 * W2 * EPL : (size_t)CPS;
-        auto col_off = [&](int gx) {  // lane offset of row 0 in the column of groups starting at gx
+        auto col_off = [&](int gx) {  // lane byte offset of row 0 in the column of groups starting at gx
           int x = gx + lx;
           x = x < W2 ? x : W2 - 1;  // padded positions re-read the last column; their results land in no box column that is read
-          return (unsigned)lg * GSTR + (unsigned)x * PSTR;
+          return ((unsigned)lg * GSTR + (unsigned)x * PSTR) * (unsigned)sizeof(T);
         };
         auto load_group = [&](frag (&dstf)[KS], unsigned coff, int y) __attribute__((always_inline)) {
-          const unsigned off = (coff + (unsigned)y * YSTR) * (unsigned)sizeof(T);  // bytes
+          const unsigned off = coff + (unsigned)y * (YSTR * (unsigned)sizeof(T));  // bytes; the row term is scalar
 #pragma unroll
           for (int s = 0; s < KS; s++)
             dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
         };
         if (nit > 0) {
           // The loop body is branch-free around its loads (a branch around a load makes hipcc wait for nearly every
-          // outstanding load at each use): the trip count is rounded up to a multiple of PF and the cursors stop at the
-          // last group, which the surplus steps load and store again.
+          // outstanding load at each use): the trip count is rounded up to a multiple of PF and the load cursor stops at
+          // the last group, which the surplus steps load and store again.  Slot j remembers which group it holds.
           frag bq[PF][KS];
-          int yl = y0w, gxl = TX0, li = 0;  // load cursor
+          int ys[PF], gqs[PF];              // row and column (relative to TX0) of the group in slot j (scalar)
+          int yl = y0w, gql = 0, li = 0;    // load cursor
           unsigned cofl = col_off(TX0);
-          auto advance_load = [&]() __attribute__((always_inline)) {
+          auto issue = [&](int j) __attribute__((always_inline)) {
+            load_group(bq[j], cofl, yl);
+            ys[j] = yl; gqs[j] = gql;
             if (li < nit - 1) {
               li++;
               yl += CO_NW;
-              if (yl > TY1) { yl = y0w; gxl += 16; cofl = col_off(gxl); }
+              if (yl > TY1) { yl = y0w; gql += 16; cofl = col_off(TX0 + gql); }
             }
           };
 #pragma unroll
-          for (int j = 0; j < PF; j++) {
-            load_group(bq[j], cofl, yl);
-            advance_load();
-          }
+          for (int j = 0; j < PF; j++) issue(j);
           CO_STAMP(2);
-          // Every fragment is multiplied with both sub-blocks; rows / columns outside a pixel's box are dropped by the
-          // store's range checks.
-          int y = y0w, gq = 0, ci = 0;  // compute cursor; gq = group column - TX0
+          // Column masks (wave-uniform 64-bit values, recomputed when the column of groups changes): which lanes' first /
+          // second pair of positions falls into the columns of their pixel's box.  A store then costs one row compare.
+          // Positions right of the map (the last column of groups re-reads column W2 - 1 for them) are not stored: their
+          // patch entries keep the zeros of phase 0.  A pair straddling the edge (odd W2) stores a zero as its second half.
+          unsigned long long colA[CO_SB], colB[CO_SB];
+          bool strad1 = false, strad3 = false;  // this lane's position 1 / 3 is the first one right of the map
+          int curq = -1;
           for (int it = 0; it < nit; it += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
@@ -391,22 +410,33 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
               for (int s = 0; s < KS; s++)
 #pragma unroll
                 for (int m = 0; m < CO_SB; m++) d[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[j][s], a[m][s], d[m], 0, 0, 0);
-              load_group(bq[j], cofl, yl);
-              advance_load();
+              const int y = ys[j], gq = gqs[j];
+              issue(j);
+              if (gq != curq) {  // wave-uniform
+                curq = gq;
+                const int xa = TX0 + gq + 4 * lg;  // map column of this lane's first position
+#pragma unroll
+                for (int m = 0; m < CO_SB; m++) {
+                  const int qx = sq0[m] + gq;
+                  colA[m] = __builtin_amdgcn_ballot_w64((unsigned)qx <= (unsigned)swl[m] && xa < W2);
+                  colB[m] = __builtin_amdgcn_ballot_w64((unsigned)(qx + 2) <= (unsigned)swl[m] && xa + 2 < W2);
+                }
+                strad1 = xa + 1 == W2; strad3 = xa + 3 == W2;
+              }
+              if (__builtin_amdgcn_ballot_w64(strad1 || strad3) != 0) {  // wave-uniform; only in the last column of groups of an odd-width map
+#pragma unroll
+                for (int m = 0; m < CO_SB; m++) {
+                  d[m][1] = strad1 ? 0.f : d[m][1];
+                  d[m][3] = strad3 ? 0.f : d[m][3];
+                }
+              }
               const int yg = y * CO_BOXP + gq;  // scalar
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) {
-                if ((unsigned)(y - sylo[m]) < (unsigned)sbh[m]) {
-                  float* dst = patch + sb[m] + yg;
-                  const int qx = sq0[m] + gq;
-                  if ((unsigned)qx <= (unsigned)swl[m]) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0], d[m][1]);
-                  if ((unsigned)(qx + 2) <= (unsigned)swl[m]) *reinterpret_cast<float2*>(dst + 2) = make_float2(d[m][2], d[m][3]);
-                }
-              }
-              if (ci < nit - 1) {
-                ci++;
-                y += CO_NW;
-                if (y > TY1) { y = y0w; gq += 16; }
+                const unsigned long long rowm = __builtin_amdgcn_ballot_w64((unsigned)(y - sylo[m]) < (unsigned)sbh[m]);
+                float* dst = sbp[m] + yg;
+                if (__builtin_amdgcn_inverse_ballot_w64(rowm & colA[m])) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0], d[m][1]);
+                if (__builtin_amdgcn_inverse_ballot_w64(rowm & colB[m])) *reinterpret_cast<float2*>(dst + 2) = make_float2(d[m][2], d[m][3]);
               }
             }
           }
@@ -416,65 +446,62 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
     }
     __syncthreads();
 
-    // ---- phase 2: sample the patches of the own sub-block ----
+    // ---- phase 2: sample the patches of the wave's own pixels ----
     float res[CO_QP][TI];
     {
       CO_FRESH_LANE();
-      int tix[TI], tiy[TI];
+      int tix[TI], tiy[TI];  // lanes past the last tap repeat it (their results are not stored)
 #pragma unroll
       for (int i = 0; i < TI; i++) {
-        const int t = lx + 16 * i;
+        int t = lx + 16 * i;
+        t = t < NT ? t : NT - 1;
         tix[i] = t / RD;
         tiy[i] = t - tix[i] * RD;
       }
 #pragma unroll
       for (int q = 0; q < CO_QP; q++) {
         const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
-        const bool pv = h1 < H1 && w1r < W1;
         const int4 pb = *reinterpret_cast<const int4*>(pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4);  // row-uniform
-        const int xal = pb.x & ~1, ylo = pb.y;
         const bool has_patch = pb.w != 0, fallback = pb.z < 0;
-        const float* const Dp = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP;
+        // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
+        const float* const D0 = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
-        // zero-offset levels: one sample position per pixel — floor, fraction and the four weights once per pass
-        const float zfx = floorf(cx), zfy = floorf(cy);
-        const float zdx = cx - zfx, zdy = cy - zfy;
-        const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
+        if (zo) {
+          // one sample position per pixel: floor, fraction and the four weights once per pass (products and order are bilerp()'s)
+          const float zfx = floorf(cx), zfy = floorf(cy);
+          const float zdx = cx - zfx, zdy = cy - zfy;
+          const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
+          const float* const Dz = D0 + ((int)zfy - R) * CO_BOXP + ((int)zfx - R);
 #pragma unroll
-        for (int i = 0; i < TI; i++) {
-          const bool tv = pv && lx + 16 * i < NT;
-          float fxs, fys, dx, dy;
-          if (zo) {
-            fxs = zfx; fys = zfy; dx = zdx; dy = zdy;
-          } else {
+          for (int i = 0; i < TI; i++) {
+            float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+            if (has_patch) {
+              const float* D = Dz + tiy[i] * CO_BOXP + tix[i];
+              q11 = D[0]; q21 = D[1]; q12 = D[CO_BOXP]; q22 = D[CO_BOXP + 1];
+            }
+            res[q][i] = q11 * zw11 + q21 * zw21 + q12 * zw12 + q22 * zw22;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TI; i++) {
             const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;
-            fxs = floorf(xs); fys = floorf(ys);
-            dx = xs - fxs; dy = ys - fys;  // :87-88
+            const float fxs = floorf(xs), fys = floorf(ys);
+            const float dx = xs - fxs, dy = ys - fys;  // :87-88
+            const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
+            float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+            if (has_patch) {
+              const float* D = D0 + h2 * CO_BOXP + w2;
+              q11 = D[0]; q21 = D[1]; q12 = D[CO_BOXP]; q22 = D[CO_BOXP + 1];
+            } else if (fallback) {  // box larger than a patch: this tap's four corner dots, channels in order, per-corner zero padding
+              const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
+              const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
+              const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
+                                               (by0 && bx0 ? 1 : 0) | (by0 && bx1 ? 2 : 0) | (by1 && bx0 ? 4 : 0) | (by1 && bx1 ? 8 : 0),
+                                               p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
+              q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+            }
+            res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117
           }
-          const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
-          const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
-          const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
-          const bool b11 = by0 && bx0, b21 = by0 && bx1, b12 = by1 && bx0, b22 = by1 && bx1;
-          float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-          if (tv && has_patch) {
-            // the four corners are read unconditionally and padded by selects: an in-bounds corner always lies inside the
-            // pixel's box; the others read whatever is there (inside the LDS allocation: CO_GUARD floats in front of the
-            // patches cover a top-left corner one row / column before the box, the tables behind them the overshoot)
-            const int idx = ((by0 || by1) && (bx0 || bx1)) ? (h2 - ylo) * CO_BOXP + (w2 - xal) : 0;
-            const float* D = Dp + idx;
-            const float d0 = D[0], d1 = D[1], d2 = D[CO_BOXP], d3 = D[CO_BOXP + 1];
-            q11 = b11 ? d0 : 0.f;
-            q21 = b21 ? d1 : 0.f;
-            q12 = b12 ? d2 : 0.f;
-            q22 = b22 ? d3 : 0.f;
-          } else if (tv && fallback) {
-            const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
-                                             (b11 ? 1 : 0) | (b21 ? 2 : 0) | (b12 ? 4 : 0) | (b22 ? 8 : 0),
-                                             p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
-            q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
-          }
-          if (zo) res[q][i] = q11 * zw11 + q21 * zw21 + q12 * zw12 + q22 * zw22;
-          else res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117, per-corner zero padding
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -589,7 +616,7 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   p.coords = coords; p.corr = corr;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.lvl0 = lvl0; p.Ltot = Ltot; p.f2_chunked = f2_chunked; p.ii = ii; p.jj = jj;
-  const bool pre = env_int("LGU_LOWMEM_COOP_PRE", 0) != 0;
+  const bool pre = env_int("LGU_LOWMEM_COOP_PRE", 1) != 0;  // debug / A-B only: 0 = the 4-waves-per-SIMD build without the look-ahead
 #define LGU_CO_CASE(RV, KSV) \
   if (radius == RV && C == 32 * KSV) return pre ? launch_coop<RV, KSV, true>(p, st) : launch_coop<RV, KSV, false>(p, st);
   LGU_CO_CASE(3, 4) LGU_CO_CASE(1, 4) LGU_CO_CASE(2, 4)
