@@ -119,18 +119,23 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
   asm volatile("" : "+v"(lane));        \
   const int lx = lane & 15, lg = lane >> 4;
 
-// PRE: a level's offsets are requested one step ahead of their use (16 more registers: compiled for 3 waves per SIMD
-// instead of 4).
-template <int R, int KS, bool PRE>
-__global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(const CoParams p) {
-  constexpr bool CO_PREFETCH = PRE;
+// Compiled for 3 waves per SIMD (168 registers): at 4 (128) the look-ahead of the offsets does not fit and the kernel
+// spills; measured 141 against 107 us for BASELINE config 4.
+constexpr int CO_WPS = 3;
+template <int R, int KS>
+__global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const CoParams p_arg) {
+  // The parameter block is read where it lies (the kernarg segment: the only argument, at offset 0), so per-level
+  // fields are scalar loads at a computed offset instead of select chains over registers that do not fit the SGPR file.
+  typedef const CoParams __attribute__((address_space(4))) CoParamsK;
+  CoParamsK& p = *(CoParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)p_arg;
   typedef _Float16 T;
   typedef cohalf8 frag;
   constexpr int CPS = 32, EPL = 8;
   constexpr int RD = 2 * R + 1, NT = RD * RD, C = CPS * KS;
   constexpr int TI = (NT + 15) / 16;
   constexpr int CEN = R * RD + R;
-  constexpr int PF = 2;  // position fragments in flight per wave
+  constexpr int PF = 2;  // position fragments in flight per wave (3 do not fit the registers: 120 against 107 us)
   extern __shared__ float smem[];
   float* const patch = smem + CO_GUARD;                                   // [CO_NPX][CO_PP]
   int* const pbox = reinterpret_cast<int*>(patch + CO_NPX * CO_PP);       // [CO_NPX][xlo, ylo, bw, bh]
@@ -145,10 +150,7 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
   if (item >= p.n_fused) {
     const int u = item - p.n_fused, grp = u / p.n_split;
     item = p.n_fused + (u - grp * p.n_split);
-    lv0 = p.gl0[0]; lv1 = p.gl0[1];
-#pragma unroll
-    for (int k = 1; k < CO_MAXL; k++)
-      if (grp == k) { lv0 = p.gl0[k]; lv1 = p.gl0[k + 1]; }
+    lv0 = p.gl0[grp]; lv1 = p.gl0[grp + 1];
   }
   if (p.xcd_map) {
     const int xcd = item & 7, slot = item >> 3;
@@ -172,10 +174,7 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
   // after the sampling of the level before it, so they travel during that level's write-out and the barrier (held across
   // a whole zero-offset level they cost 16 registers where the kernel has none to spare).
   auto level_offsets = [&](int l) -> float* {  // workgroup-uniform; reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
-    float* o = p.offset[0];
-#pragma unroll
-    for (int k = 1; k < CO_MAXL; k++)
-      if (l == k) o = p.offset[k];
+    float* o = p.offset[l];
     return o ? o + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
   };
   float2 o0[CO_QP][TI];
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
       cv0[q] = cbase[pv ? (size_t)h1 * W1 + w1r : 0];
     }
   }
-  if (CO_PREFETCH) request_offsets(lv1 - 1);
+  request_offsets(lv1 - 1);
   {
     CO_FRESH_LANE();
 #pragma unroll
@@ -229,16 +228,12 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
   }
 
   for (int lvl = lv1 - 1; lvl >= lv0; lvl--) {
-    const T* fmap2 = p.fmap2[0];
-    int H2 = p.H2[0], W2 = p.W2[0];
-#pragma unroll
-    for (int l = 1; l < CO_MAXL; l++)
-      if (lvl == l) { fmap2 = p.fmap2[l]; H2 = p.H2[l]; W2 = p.W2[l]; }
+    const T* const fmap2 = p.fmap2[lvl];
+    const int H2 = p.H2[lvl], W2 = p.W2[lvl];
     const float cscale = __builtin_ldexpf(1.0f, -(p.lbase + lvl));
     const T* const F2 = fmap2 + f2i * H2 * W2 * C;
     float* const obase = level_offsets(lvl);  // null = zero offsets
     const bool zo = obase == nullptr;  // workgroup-uniform
-    if (!CO_PREFETCH) request_offsets(lvl);
 
     // ---- phase 0: tap boxes of the wave's own pixels ----
     // A pixel's box is the extent of ALL its taps' corners, NOT clipped to the map (<= 16 x 16 for |offset| < 4, whatever
@@ -472,43 +467,47 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
           const float zdx = cx - zfx, zdy = cy - zfy;
           const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
           const float* const Dz = D0 + ((int)zfy - R) * CO_BOXP + ((int)zfx - R);
+          float q11[TI], q21[TI], q12[TI], q22[TI];  // all reads of the pass in flight before the first blend
 #pragma unroll
           for (int i = 0; i < TI; i++) {
-            float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+            q11[i] = q21[i] = q12[i] = q22[i] = 0.f;
             if (has_patch) {
               const float* D = Dz + tiy[i] * CO_BOXP + tix[i];
-              q11 = D[0]; q21 = D[1]; q12 = D[CO_BOXP]; q22 = D[CO_BOXP + 1];
+              q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
             }
-            res[q][i] = q11 * zw11 + q21 * zw21 + q12 * zw12 + q22 * zw22;
           }
+#pragma unroll
+          for (int i = 0; i < TI; i++) res[q][i] = q11[i] * zw11 + q21[i] * zw21 + q12[i] * zw12 + q22[i] * zw22;
         } else {
+          float q11[TI], q21[TI], q12[TI], q22[TI], dxs[TI], dys[TI];
 #pragma unroll
           for (int i = 0; i < TI; i++) {
             const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;
             const float fxs = floorf(xs), fys = floorf(ys);
-            const float dx = xs - fxs, dy = ys - fys;  // :87-88
+            dxs[i] = xs - fxs; dys[i] = ys - fys;  // :87-88
             const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
-            float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
+            q11[i] = q21[i] = q12[i] = q22[i] = 0.f;
             if (has_patch) {
               const float* D = D0 + h2 * CO_BOXP + w2;
-              q11 = D[0]; q21 = D[1]; q12 = D[CO_BOXP]; q22 = D[CO_BOXP + 1];
+              q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
             } else if (fallback) {  // box larger than a patch: this tap's four corner dots, channels in order, per-corner zero padding
               const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
               const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
               const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
                                                (by0 && bx0 ? 1 : 0) | (by0 && bx1 ? 2 : 0) | (by1 && bx0 ? 4 : 0) | (by1 && bx1 ? 8 : 0),
                                                p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
-              q11 = qq.x; q21 = qq.y; q12 = qq.z; q22 = qq.w;
+              q11[i] = qq.x; q21[i] = qq.y; q12[i] = qq.z; q22[i] = qq.w;
             }
-            res[q][i] = bilerp(q11, q21, q12, q22, dx, dy);  // :114-117
           }
+#pragma unroll
+          for (int i = 0; i < TI; i++) res[q][i] = bilerp(q11[i], q21[i], q12[i], q22[i], dxs[i], dys[i]);  // :114-117
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       CO_STAMP(4);
     }
-    if (CO_PREFETCH) request_offsets(lvl - 1);  // this level's offsets are consumed: the next level's travel during the write-out
+    request_offsets(lvl - 1);  // this level's offsets are consumed: the next level's travel during the write-out
 
     // ---- write-out: corr[b][n][ix][iy][h1][w1]; the wave's own patches become its [tap][pixel] transpose tile ----
     {
@@ -544,10 +543,9 @@ __global__ __launch_bounds__(kWave* CO_NW, PRE ? 3 : 4) void lowmem_coop_kernel(
 }
 #undef CO_FRESH_LANE
 
-template <int R, int KS, bool PRE>
+template <int R, int KS>
 static int launch_coop(CoParams p, hipStream_t st) {
-  auto kern = lowmem_coop_kernel<R, KS, PRE>;
-  constexpr int CO_WPS = PRE ? 3 : 4;
+  auto kern = lowmem_coop_kernel<R, KS>;
   const size_t lds = sizeof(float) * (size_t)CO_LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {
@@ -616,9 +614,8 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   p.coords = coords; p.corr = corr;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.lvl0 = lvl0; p.Ltot = Ltot; p.f2_chunked = f2_chunked; p.ii = ii; p.jj = jj;
-  const bool pre = env_int("LGU_LOWMEM_COOP_PRE", 1) != 0;  // debug / A-B only: 0 = the 4-waves-per-SIMD build without the look-ahead
 #define LGU_CO_CASE(RV, KSV) \
-  if (radius == RV && C == 32 * KSV) return pre ? launch_coop<RV, KSV, true>(p, st) : launch_coop<RV, KSV, false>(p, st);
+  if (radius == RV && C == 32 * KSV) return launch_coop<RV, KSV>(p, st);
   LGU_CO_CASE(3, 4) LGU_CO_CASE(1, 4) LGU_CO_CASE(2, 4)
   LGU_CO_CASE(3, 2) LGU_CO_CASE(1, 2) LGU_CO_CASE(2, 2)
   LGU_CO_CASE(3, 1) LGU_CO_CASE(1, 1) LGU_CO_CASE(2, 1)

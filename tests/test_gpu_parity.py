@@ -1635,3 +1635,45 @@ def test_randomized_differential_lowmem(lgu, seed):
     tag = (B, H1, W1, C, radius, L, sigma, osc)
     assert float((got_f - want).abs().max()) <= 1e-5, tag
     assert float((got_h - want).abs().max()) <= 1e-5, tag
+
+
+@pytest.mark.parametrize("shape", [(16, 60, 80, 32), (3, 21, 27, 64), (9, 10, 13, 128)])
+def test_lowmem_coop_kernel_scheduling_modes_and_the_one_wave_kernel(lgu, oracle, shape, monkeypatch):
+    """csrc/lowmem_coop.hip (production for half maps with C <= 128): the same call served (a) with whole rounds of
+    workgroups fused over all levels and the remainder split by level group (the default rule: BASELINE config 4's 2 400
+    tiles over 768 slots), (b) all fused, (c) all split gives BIT-IDENTICAL results (same products, same order, other
+    work units), equals the one-wave-per-block kernel of lowmem_mfma.hip to summation order, and the C oracle on the
+    first and the last edge.  Shapes: config-4 size at C = 32, ragged sizes (W1 not a multiple of the 8-pixel tile, odd
+    level widths: pairs of positions straddling the right edge), 9 edges (XCD dealing with a tail).  sigma = 6: a third
+    of the taps fall outside the map (zero-filled border patches)."""
+    B, H, W, C = shape
+    torch.manual_seed(B * 100 + W)
+    L, radius = 4, 3
+    f1 = (torch.randn(B, H, W, C, device="cuda") * 0.125).half()
+    f2s = [(torch.randn(B, max(H >> l, 1), max(W >> l, 1), C, device="cuda") * 0.125).half() for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 6 * torch.randn(B, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = (4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    o1 = ((4 * torch.tanh(torch.randn(B, H, W, 7, 7, 2, device="cuda")) + o0) / 2).contiguous()
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0.clone(), o1.clone(), None, None], radius)
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    default = run()
+    assert torch.equal(default, run(LGU_LOWMEM_COOP_SPLIT="0"))
+    assert torch.equal(default, run(LGU_LOWMEM_COOP_SPLIT="1"))
+    old = run(LGU_LOWMEM_COOP="0")
+    assert float((default - old).abs().max()) <= 1e-5
+    for b in (0, B - 1):
+        for l, off in enumerate([o0, o1, None, None]):
+            # the reference reads offset[b * n] (lowMem_defSample.cu:80-83): with S = 1 every edge samples with edge 0's offsets
+            o_np = host(off[0:1]).copy() if off is not None else np.zeros((1, H, W, 7, 7, 2), np.float32)
+            want, = oracle.lowMem_defSample(host(f1[b:b + 1].float()), host(f2s[l][b:b + 1].float()),
+                                            host(coords[b:b + 1] / 2 ** l), o_np, radius)
+            got = host(default[b:b + 1, :, l * 49:(l + 1) * 49]).reshape(want.shape)
+            assert np.abs(got - want).max() <= 1e-5, (b, l)
