@@ -311,12 +311,13 @@ def lowmem_roofline(S, dev_ms):
     achieved = flop_unit * S["units"] / kern_s / 1e12
     hbm_unit = (1 + 1.328) * S["C"] * 2 + 784 + 784 + 8  # half maps: fmap1 + fmap2 pyramid, out, offsets of 2 levels, coords
     return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-            "traffic": None, "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem kernels (csrc/lowmem_*.hip)",
+            "traffic": None, "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
             "device_ms_per_step": dev_ms,
             "hbm_compulsory_bytes_per_unit": hbm_unit, "hbm_compulsory_GBps": hbm_unit * S["units"] / kern_s / 1e9,
             "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "
-                    "launch is bound by moving the swept windows of fmap2 to the matrix cores (DESIGN.md §3.4), not by the "
-                    "MFMA rate"}
+                    "launch is bound by instruction issue and latency of the per-pixel box / sampling phases around the "
+                    "contraction at 12 waves per CU (DESIGN.md §3.4), not by the MFMA rate: the matrix cores are busy ~12 % "
+                    "of the time (PMC, profiles/)"}
 
 
 def lowmem_cpu_baseline(S):
@@ -377,7 +378,7 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
                "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16 features, f32 accumulate", "data": "synthetic",
                "config": {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, one chunk of "
-                                      "%d edges per GPU, all levels in one call (levels with offsets + zero-offset levels: 2 launches), "
+                                      "%d edges per GPU, all levels in ONE launch (4 x 8 pixel tiles, four waves share the swept window), "
                                       "target maps chunk-planar as AltCorrBlock stores them" % S["B"],
                           "edges_per_gpu": S["B"], "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)"},
                "roofline": roof,

@@ -334,6 +334,11 @@ int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* f
  *                         diag += ep + lm*diag, blocked Cholesky and both triangular solves in one workgroup with the
  *                         matrix in LDS.  A (6P x 6P, row-major double, symmetric), b (6P) double; x (P,6) float; x = 0
  *                         if the damped matrix is not positive definite.  6P <= 192 (the matrix lives in LDS as a packed lower triangle), otherwise LGU_E_UNSUPPORTED.
+ * lgu_ba_solve_blocked_f64  the same solve for any window size (csrc/ba_chol.hip): blocked Cholesky over 32-column panels
+ *                         (every workgroup factorises the diagonal block in LDS, one thread per row below it; 64 x 64 tiles
+ *                         for the trailing update), the right-hand side carried as row 6P of the matrix, back substitution
+ *                         in one workgroup.  A is OVERWRITTEN with the factor; work >= lgu_ba_solve_blocked_work_doubles(P)
+ *                         doubles; x = 0 if not positive definite.
  * lgu_ba_pose_retr_f32    pose_retr_kernel (:898-931): poses[k] <- exp(dx[k-t0]) * poses[k], k in [t0, t1).
  * lgu_ba_disp_retr_f32    disp_retr_kernel (:933-946): disps[inds[b]] += dz[b]. */
 int lgu_ba_build_f32(const float* targets, const float* weights, const float* poses, const float* disps,
@@ -353,6 +358,8 @@ int lgu_ba_eet_f32(const float* E, const float* Q, const long long* idx, float* 
 int lgu_ba_ev_f32(const float* E, const float* Q, const float* w, const long long* kk, float* v, int n, int D, void* stream);
 int lgu_ba_evt_f32(const float* E, const float* x, const long long* idx, float* dw, int n, int D, int P, void* stream);
 int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double lm, double ep, void* stream);
+long long lgu_ba_solve_blocked_work_doubles(int P);
+int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work, int P, double lm, double ep, void* stream);
 /* lgu_ba_assemble_f64: the four scatter sums of one iteration, their zero-fills and the blocked -> dense permutation in one
  * launch: block d = bi * P + bj of the system = sum of Hs rows [hptr[d], hptr[d+1]) of hidx - sum of S rows (sptr, sidx;
  * S may be NULL: motion only), written to Ad (6P x 6P row-major, double); b (6P) likewise from vs / sv.  CSR tables cover

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lgu_ba_ev_f32": [_vp] * 5 + [_int] * 2 + [_vp],
     "lgu_ba_evt_f32": [_vp] * 4 + [_int] * 3 + [_vp],
     "lgu_ba_solve_f64": [_vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _vp],
+    "lgu_ba_solve_blocked_f64": [_vp, _vp, _vp, _vp, _int, ctypes.c_double, ctypes.c_double, _vp],
     "lgu_ba_pose_retr_f32": [_vp] * 2 + [_int] * 2 + [_vp],
     "lgu_ba_assemble_f64": [_vp] * 14 + [_int, _vp],
     "lgu_ba_disp_retr_f32": [_vp] * 3 + [_int] * 2 + [_vp],
@@ -100,6 +101,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, let it surface
         fn.argtypes = argtypes
         fn.restype = _int
+    lib.lgu_ba_solve_blocked_work_doubles.restype = ctypes.c_longlong
+    lib.lgu_ba_solve_blocked_work_doubles.argtypes = [_int]
     lib.lgu_offsets_finalize_scratch_bytes.restype = ctypes.c_longlong
     lib.lgu_offsets_finalize_scratch_bytes.argtypes = [_int]
     lib.lgu_version.restype = ctypes.c_char_p

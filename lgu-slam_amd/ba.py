@@ -11,6 +11,8 @@ depth frame), built once per call from ii / jj exactly as the reference's schur_
 PARITY UNPINNED (the reference needs Eigen, absent in this image): checked against oracle/ba_oracle.py, which is itself
 pinned only by self-consistency tests (tests/test_ba.py).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -214,8 +216,13 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
                                            _ptr(Ad), _ptr(b), P, st), "ba assembly")
         dx = torch.empty((P, 6), dtype=f32, device=dev)
         rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
-        if rc == _lib.LGU_E_UNSUPPORTED:   # more than 32 poses in the window: library Cholesky on the device
-            dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+        if rc == _lib.LGU_E_UNSUPPORTED:   # more than 32 poses in the window: blocked Cholesky over the matrix in HBM (csrc/ba_chol.hip)
+            if os.environ.get("LGU_BA_LIBRARY_SOLVE", "0") != "0":   # debug / A-B only: the library factorisation of rounds 1-2
+                dx = _solve(Ad, b.view(-1), lm, ep).view(P, 6).to(f32).contiguous()
+            else:
+                work = torch.empty(int(lib.lgu_ba_solve_blocked_work_doubles(P)), dtype=f64, device=dev)
+                _lib.check(lib.lgu_ba_solve_blocked_f64(_ptr(Ad), _ptr(b), _ptr(dx), _ptr(work), P, float(lm), float(ep), st),
+                           "ba blocked solve")   # Ad is this iteration's own copy: overwritten with the factor
         else:
             _lib.check(rc, "ba solve")
         if not motion_only:

@@ -1,0 +1,219 @@
+// ba_chol.hip — reduced camera system of a large window: damping + blocked Cholesky + both triangular solves on the
+// device in double, for 6 P > 192 (the single-workgroup solver of ba.hip holds the matrix in LDS and stops there).
+//
+// Reference: SparseBlock::solve (src/droid_kernels.cu:1206-1231) — Eigen SimplicialLLT on the HOST, in double, zero update
+// when the factorisation fails.  Round 1 / 2 used the library factorisation (rocSOLVER through torch.linalg.cholesky_ex):
+// 3.5 ms per iteration at 1194 x 1194, a chain of ~60 small unblocked-panel launches.  Here, per block column of 32:
+//   panel   every workgroup factorises the 32 x 32 diagonal block redundantly in LDS (no extra launch, no dependency on
+//           another workgroup), then each THREAD solves one row below it against the block (row in registers, the block
+//           as LDS broadcasts);
+//   update  64 x 64 tiles of the trailing lower triangle, one workgroup each, panels staged in LDS.
+// The right-hand side rides along as row n of the matrix, so the forward substitution is part of the factorisation;
+// the back substitution is one workgroup (column blocks from the last to the first, 1024 threads on the updates).
+// Parity: unpinned, like the rest of the bundle adjustment (the reference needs Eigen, absent here); held to an fp64
+// library solve in tests/test_ba.py.
+#include "lgu_common.hpp"
+
+namespace lgu {
+
+constexpr int CH_NB = 32;    // block column width
+constexpr int CH_T = 256;    // threads of the panel / update kernels
+constexpr int CH_TILE = 64;  // trailing-update tile
+constexpr int CH_BT = 1024;  // threads of the back substitution
+
+// A[i][i] += ep + lm * A[i][i]  (L.diagonal() += ep + lm * L.diagonal(), :1213); row n := b; flag := 0
+__global__ void chol_prepare_kernel(double* A, const double* __restrict__ b, double* ext, int* flag, int n, double lm, double ep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *flag = 0;
+  if (i < n) {
+    const double d = A[(size_t)i * n + i];
+    A[(size_t)i * n + i] = d + (ep + lm * d);
+    ext[i] = b[i];
+  }
+}
+
+// Row r of the working matrix: r < n is a row of A, r == n is the right-hand side.
+__device__ __forceinline__ double* chol_row(double* A, double* ext, int n, int r) { return r < n ? A + (size_t)r * n : ext; }
+
+__global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext, double* stage, int* flag, int n, int k0) {
+  extern __shared__ double chol_smem[];
+  double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(chol_smem);               // [CH_NB][CH_NB + 1]
+  double (*Bs)[CH_T] = reinterpret_cast<double (*)[CH_T]>(chol_smem + CH_NB * (CH_NB + 1));  // [CH_NB][CH_T]: column c of thread t's row
+  const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
+  const int t = threadIdx.x;
+  // this thread's row behind the block (r == n: the right-hand side), requested before the block is factorised
+  const int r = k0 + w + blockIdx.x * CH_T + t;
+  double* const rp = r <= n ? chol_row(A, ext, n, r) + k0 : nullptr;
+  if (rp)
+    for (int j = 0; j < w; j++) Bs[j][t] = rp[j];
+  // diagonal block, lower triangle; padded to CH_NB with the identity
+  for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) {
+    const int i = idx / CH_NB, j = idx - i * CH_NB;
+    double v = i == j ? 1.0 : 0.0;
+    if (i < w && j < w && j <= i) v = A[(size_t)(k0 + i) * n + k0 + j];
+    D[i][j] = v;
+  }
+  __syncthreads();
+  for (int j = 0; j < w; j++) {
+    if (t == 0) {
+      double d = D[j][j];
+      if (!(d > 0.0) || !(d < 1e300)) { *flag = 1; d = 1.0; }  // not positive definite: finish on a harmless pivot, x = 0 at the end
+      D[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    if (t > j && t < w) D[t][j] /= D[j][j];
+    __syncthreads();
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) {
+      const int i = idx / CH_NB, k = idx - i * CH_NB;
+      if (k > j && i >= k && i < w) D[i][k] -= D[i][j] * D[k][j];
+    }
+    __syncthreads();
+  }
+  // The factor of the block goes to a staging area, not into A: other workgroups of this launch may still be reading the
+  // block.  The update launch that follows copies it in.
+  if (blockIdx.x == 0)
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) stage[idx] = D[idx / CH_NB][idx % CH_NB];
+  // rows behind the block: X L_kk^T = A_ik, one row per thread; the row lives in LDS (column-major over the threads:
+  // conflict-free), the block entries are broadcasts.  (With the row in registers the fully unrolled 32 x 32 solve made
+  // hipcc hold the whole block in registers too: 512 VGPRs and 600 spilled.)
+  if (!rp) return;
+  for (int j = 0; j < w; j++) {
+    double v = Bs[j][t];
+    for (int p = 0; p < j; p++) v -= Bs[p][t] * D[j][p];
+    v /= D[j][j];
+    Bs[j][t] = v;
+    rp[j] = v;
+  }
+}
+
+// A[i][j] -= sum_t L[i][k0 + t] L[j][k0 + t] for the rows / columns behind the panel (rows include the right-hand side),
+// tiles on or below the diagonal.  Thread (ty, tx) owns a 4 x 4 sub-tile.
+__global__ __launch_bounds__(CH_T) void chol_update_kernel(double* A, double* ext, const double* __restrict__ stage, int n, int k0, int w) {
+  if (blockIdx.x > blockIdx.y) return;  // x = column tile, y = row tile
+  if (blockIdx.x == 0 && blockIdx.y == 0)  // the factor of the diagonal block, staged by the panel launch
+    for (int idx = threadIdx.x; idx < CH_NB * CH_NB; idx += CH_T) {
+      const int i = idx / CH_NB, j = idx - i * CH_NB;
+      if (i < w && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = stage[idx];
+    }
+  __shared__ double Li[CH_TILE][CH_NB + 1], Lj[CH_TILE][CH_NB + 1];
+  const int k1 = k0 + w;
+  const int i0 = k1 + blockIdx.y * CH_TILE, j0 = k1 + blockIdx.x * CH_TILE;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < CH_TILE * CH_NB; idx += CH_T) {
+    const int r = idx / CH_NB, c = idx - r * CH_NB;
+    const int gi = i0 + r, gj = j0 + r;
+    Li[r][c] = (gi <= n && c < w) ? chol_row(A, ext, n, gi)[k0 + c] : 0.0;
+    Lj[r][c] = (gj < n && c < w) ? A[(size_t)gj * n + k0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int ty = t / 16, tx = t % 16;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < CH_NB; c++) {
+    double li[4], lj[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) { li[a] = Li[ty * 4 + a][c]; lj[a] = Lj[tx * 4 + a][c]; }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) acc[a][b] += li[a] * lj[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int gi = i0 + ty * 4 + a;
+    if (gi > n) continue;
+    double* const rp = chol_row(A, ext, n, gi);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int gj = j0 + tx * 4 + b;
+      if (gj < n && gj <= gi) rp[gj] -= acc[a][b];
+    }
+  }
+}
+
+// L^T x = y with y = row n after the factorisation; x as float (P, 6); zeros when the factorisation failed.
+__global__ __launch_bounds__(CH_BT) void chol_backsolve_kernel(const double* __restrict__ A, const double* __restrict__ ext,
+                                                              const int* __restrict__ flag, float* __restrict__ x, int n) {
+  extern __shared__ double ys[];  // [n] right-hand side, then the current diagonal block and its solution
+  double* const Dk = ys + n;      // [CH_NB][CH_NB + 1]
+  double* const xb = Dk + CH_NB * (CH_NB + 1);
+  const int t = threadIdx.x;
+  if (*flag) {
+    for (int i = t; i < n; i += CH_BT) x[i] = 0.f;
+    return;
+  }
+  for (int i = t; i < n; i += CH_BT) ys[i] = ext[i];
+  __syncthreads();
+  const int nblk = (n + CH_NB - 1) / CH_NB;
+  for (int kb = nblk - 1; kb >= 0; kb--) {
+    const int k0 = kb * CH_NB, w = n - k0 < CH_NB ? n - k0 : CH_NB;
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_BT) {
+      const int i = idx / CH_NB, j = idx - i * CH_NB;
+      Dk[i * (CH_NB + 1) + j] = (i < w && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    if (t < kWave) {  // one wave: x_j = (y_j - sum_{i > j} L_ij x_i) / L_jj, j descending; lane i holds the running y_i
+      double v = t < w ? ys[k0 + t] : 0.0;
+      for (int j = w - 1; j >= 0; j--) {
+        const double xj = __shfl(v, j, kWave) / Dk[j * (CH_NB + 1) + j];
+        if (t == j) v = xj;
+        else if (t < j) v -= Dk[j * (CH_NB + 1) + t] * xj;
+      }
+      if (t < w) { xb[t] = v; ys[k0 + t] = v; }
+    }
+    __syncthreads();
+    // y[c] -= sum_i L[k0 + i][c] x_i for the columns in front of the block (rows of L are contiguous along c)
+    for (int c = t; c < k0; c += CH_BT) {
+      double s = 0.0;
+      for (int i = 0; i < w; i++) s += A[(size_t)(k0 + i) * n + c] * xb[i];
+      ys[c] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += CH_BT) x[i] = (float)ys[i];
+}
+
+}  // namespace lgu
+
+extern "C" {
+
+/* Doubles of workspace lgu_ba_solve_blocked_f64 needs (the right-hand side row, a flag, one staged diagonal block). */
+long long lgu_ba_solve_blocked_work_doubles(int P) { return P < 1 ? 0 : 6LL * P + 2 + 32 * 32; }
+
+/* (A + diag(ep + lm diag A)) x = b for any window size; A (6P x 6P row-major double, symmetric) is OVERWRITTEN with the
+ * factor, b is left alone, x (P, 6) float, work >= lgu_ba_solve_blocked_work_doubles(P) doubles.  x = 0 if not positive
+ * definite (the reference's behaviour when Eigen reports failure).  Enqueues ~2 launches per 32 columns on `stream`. */
+int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work, int P, double lm, double ep, void* stream) {
+  using namespace lgu;
+  if (!A || !b || !x || !work || P < 1) return LGU_E_BADARG;
+  const int n = 6 * P;
+  if (n > 16000) return LGU_E_UNSUPPORTED;  // the back substitution keeps the right-hand side in LDS
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  double* ext = work;
+  int* flag = reinterpret_cast<int*>(work + n);
+  double* stage = work + n + 2;
+  const size_t panel_lds = sizeof(double) * (CH_NB * (CH_NB + 1) + CH_NB * CH_T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chol_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, b, ext, flag, n, lm, ep);
+  for (int k0 = 0; k0 < n; k0 += CH_NB) {
+    const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
+    const int rows = n + 1 - (k0 + w);  // rows behind the block, the right-hand side included
+    hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_T - 1) / CH_T), dim3(CH_T), panel_lds, st, A, ext, stage, flag, n, k0);
+    const int nt = (rows + CH_TILE - 1) / CH_TILE;
+    hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(CH_T), 0, st, A, ext, stage, n, k0, w);
+  }
+  const size_t lds = sizeof(double) * ((size_t)n + CH_NB * (CH_NB + 1) + CH_NB);
+  hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BT), lds, st, A, ext, flag, x, n);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -329,6 +329,51 @@ def test_device_cholesky_solve_against_numpy(lgu, P):
         assert rc == lgu._lib.LGU_E_UNSUPPORTED
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [33, 40, 77, 200])
+def test_blocked_device_cholesky_solve_against_numpy(lgu, P):
+    """lgu_ba_solve_blocked_f64 (csrc/ba_chol.hip; windows of more than 32 keyframes, e.g. the 200-keyframe global BA of
+    BASELINE config 5): damping, blocked Cholesky (32-column panels, the right-hand side as row 6P), back substitution —
+    against numpy.linalg in double, on a banded-plus-loop-closure matrix shaped like a reduced camera system; sizes that
+    are and are not multiples of the panel width; not positive definite -> x = 0; A is overwritten, b is not."""
+    import ctypes
+    rng = np.random.default_rng(700 + P)
+    n = 6 * P
+    M = rng.standard_normal((n, n))
+    band = np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 30
+    M = M * band
+    M[:12, -12:] = rng.standard_normal((12, 12))           # a loop closure far off the band
+    A = M @ M.T + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    lm, ep = 1e-4, 0.1
+    Ld = A.copy()
+    Ld[np.diag_indices(n)] += ep + lm * np.diag(A)
+    want = np.linalg.solve(Ld, b)
+    lib = lgu._lib.load()
+    nwork = int(lib.lgu_ba_solve_blocked_work_doubles(P))
+    assert nwork >= n + 1
+
+    def solve(Am):
+        Ad = torch.from_numpy(np.ascontiguousarray(Am)).cuda()
+        bd = torch.from_numpy(b).cuda()
+        x = torch.full((P, 6), 7.0, dtype=torch.float32, device="cuda")
+        work = torch.empty(nwork, dtype=torch.float64, device="cuda")
+        rc = lib.lgu_ba_solve_blocked_f64(ctypes.c_void_p(Ad.data_ptr()), ctypes.c_void_p(bd.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                          ctypes.c_void_p(work.data_ptr()), P, lm, ep, None)
+        torch.cuda.synchronize()
+        assert torch.equal(bd.cpu(), torch.from_numpy(b))
+        return rc, x.cpu().numpy().reshape(-1), Ad.cpu().numpy()
+
+    rc, got, fac = solve(A)
+    assert rc == 0 and np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())      # float32 output of a double solve
+    Lw = np.linalg.cholesky(Ld)
+    assert np.abs(np.tril(fac) - Lw).max() <= 1e-9 * np.abs(Lw).max()                         # A now holds the factor
+    Abad = A.copy()
+    Abad[n // 2, n // 2] = -5.0 * np.abs(A).max()
+    rc, got, _ = solve(Abad)
+    assert rc == 0 and not got.any()
+
+
 # ---- independent check of the Jacobians: central finite differences of the projection ---------------------------------
 # Nothing below touches oracle/ba_oracle.py: the forward model (SE3 exponential, quaternion action on a homogeneous point
 # with disparity, pinhole projection) is written out here in fp64 from the geometry, and every output of the build kernel
