@@ -38,10 +38,13 @@ __device__ __forceinline__ double* chol_row(double* A, double* ext, int n, int r
 __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext, double* stage, int* flag, int n, int k0) {
   extern __shared__ double chol_smem[];
   double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(chol_smem);               // [CH_NB][CH_NB + 1]
-  double (*Bs)[CH_T] = reinterpret_cast<double (*)[CH_T]>(chol_smem + CH_NB * (CH_NB + 1));  // [CH_NB][CH_T]: column c of thread t's row
+  double* const dsq = chol_smem + CH_NB * (CH_NB + 1);                                        // [CH_NB] roots of the pivots
+  double (*Bs)[CH_T + 1] = reinterpret_cast<double (*)[CH_T + 1]>(dsq + CH_NB);                // [CH_NB][CH_T + 1]: column c of thread t's row 
   const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
   const int t = threadIdx.x;
-  // this thread's row behind the block (r == n: the right-hand side), requested before the block is factorised
+  // this thread's row behind the block (r == n: the right-hand side), requested before the block is factorised.
+  // (Reading the rows cooperatively, 32 consecutive threads per row, and transposing through LDS was measured and is
+  // slower: 47 against 40 us per launch.)
   const int r = k0 + w + blockIdx.x * CH_T + t;
   double* const rp = r <= n ? chol_row(A, ext, n, r) + k0 : nullptr;
   if (rp)
@@ -55,14 +58,21 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
   }
   __syncthreads();
   for (int j = 0; j < w; j++) {
-    if (t == 0) {
+    // every thread of column j takes the root of the pivot itself (no barrier between the pivot and the scaling)
+    if (t >= j && t < w) {
       double d = D[j][j];
-      if (!(d > 0.0) || !(d < 1e300)) { *flag = 1; d = 1.0; }  // not positive definite: finish on a harmless pivot, x = 0 at the end
-      D[j][j] = sqrt(d);
+      const bool bad = !(d > 0.0) || !(d < 1e300);
+      if (bad) d = 1.0;  // not positive definite: finish on a harmless pivot, x = 0 at the end
+      d = sqrt(d);
+      if (t == j) {
+        if (bad) *flag = 1;
+        dsq[j] = d;
+      } else {
+        D[t][j] /= d;
+      }
     }
     __syncthreads();
-    if (t > j && t < w) D[t][j] /= D[j][j];
-    __syncthreads();
+    if (t == 0) D[j][j] = dsq[j];
     for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) {
       const int i = idx / CH_NB, k = idx - i * CH_NB;
       if (k > j && i >= k && i < w) D[i][k] -= D[i][j] * D[k][j];
@@ -78,9 +88,16 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
   // hipcc hold the whole block in registers too: 512 VGPRs and 600 spilled.)
   if (!rp) return;
   for (int j = 0; j < w; j++) {
-    double v = Bs[j][t];
-    for (int p = 0; p < j; p++) v -= Bs[p][t] * D[j][p];
-    v /= D[j][j];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the LDS latency of one read per product is the cost
+    int p = 0;
+    for (; p + 4 <= j; p += 4) {
+      s0 += Bs[p][t] * D[j][p];
+      s1 += Bs[p + 1][t] * D[j][p + 1];
+      s2 += Bs[p + 2][t] * D[j][p + 2];
+      s3 += Bs[p + 3][t] * D[j][p + 3];
+    }
+    for (; p < j; p++) s0 += Bs[p][t] * D[j][p];
+    const double v = (Bs[j][t] - ((s0 + s1) + (s2 + s3))) / D[j][j];
     Bs[j][t] = v;
     rp[j] = v;
   }
@@ -168,9 +185,17 @@ __global__ __launch_bounds__(CH_BT) void chol_backsolve_kernel(const double* __r
     __syncthreads();
     // y[c] -= sum_i L[k0 + i][c] x_i for the columns in front of the block (rows of L are contiguous along c)
     for (int c = t; c < k0; c += CH_BT) {
-      double s = 0.0;
-      for (int i = 0; i < w; i++) s += A[(size_t)(k0 + i) * n + c] * xb[i];
-      ys[c] -= s;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const double* const col = A + (size_t)k0 * n + c;
+      int i = 0;
+      for (; i + 4 <= w; i += 4) {
+        s0 += col[(size_t)i * n] * xb[i];
+        s1 += col[(size_t)(i + 1) * n] * xb[i + 1];
+        s2 += col[(size_t)(i + 2) * n] * xb[i + 2];
+        s3 += col[(size_t)(i + 3) * n] * xb[i + 3];
+      }
+      for (; i < w; i++) s0 += col[(size_t)i * n] * xb[i];
+      ys[c] -= (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
   }
@@ -196,7 +221,7 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
   double* ext = work;
   int* flag = reinterpret_cast<int*>(work + n);
   double* stage = work + n + 2;
-  const size_t panel_lds = sizeof(double) * (CH_NB * (CH_NB + 1) + CH_NB * CH_T);
+  const size_t panel_lds = sizeof(double) * (CH_NB * (CH_NB + 1) + CH_NB + CH_NB * (CH_T + 1));
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
