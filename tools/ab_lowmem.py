@@ -15,6 +15,7 @@ import bench  # noqa: E402
 import lgu_slam_amd  # noqa: E402
 
 ops = lgu_slam_amd.ops
+os.environ["LGU_LOWMEM_COOP"] = "0"   # this tool compares variants of the one-wave-per-block kernel (lowmem_mfma.hip)
 dev = torch.device("cuda:0")
 mts = [v for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2").split(",")]
 S = bench.lowmem_setup(ops, dev, 16, 4321)

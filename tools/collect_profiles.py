@@ -109,7 +109,9 @@ cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))] if os
 import shutil
 for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_calls.json", "%s_e2e_glue_calls.json"),
                  ("prof_init.txt", "%s_corrblock_init.txt"), ("ab_final.jsonl", "%s_ab_metric_kernel_variants.jsonl"),
-                 ("pmc_cold.txt", "%s_pmc_metric_kernel_cold.txt"), ("ab_lowmem.jsonl", "%s_ab_lowmem_levels.jsonl")):
+                 ("pmc_cold.txt", "%s_pmc_metric_kernel_cold.txt"), ("ab_lowmem.jsonl", "%s_ab_lowmem_levels.jsonl"),
+                 ("ab_lowmem_coop.jsonl", "%s_ab_lowmem_coop.jsonl"), ("co_stamps.txt", "%s_lowmem_coop_stamps.txt"),
+                 ("pmc_lowmem.txt", "%s_pmc_lowmem_kernels.txt"), ("ba_kernel_stats.csv", "%s_ba_kernel_stats.csv")):
     if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 0:
         shutil.copy(os.path.join(G, src), os.path.join(P, dst % tag))
 json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py line (cold-cache headline + extra: probe on, row-major "

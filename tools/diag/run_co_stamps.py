@@ -55,7 +55,7 @@ s = stamps.cpu().numpy().astype(np.float64).reshape(nwg * 4, 4, 8)[:, :nl, :6] *
 live = s[:, :, 5] > 0   # [wave][level]: levels that wave served
 t0 = s[:, :, 0][live].min()
 print("levels %s: %d waves, kernel span %.1f us" % (levels, int(live.any(1).sum()), s[:, :, 5].max() - t0))
-names = ["offsets + boxes", "barrier + window + first loads", "sweep", "offsets again + barrier + sampling", "write-out"]
+names = ["boxes (+ wait for the offsets)", "barrier + window + first loads", "sweep", "barrier + sampling", "write-out"]
 for k in range(nl):
     sk = s[live[:, k], k, :]
     d = np.diff(sk, axis=1)
