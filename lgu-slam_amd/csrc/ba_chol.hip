@@ -5,11 +5,13 @@
 // when the factorisation fails.  Round 1 / 2 used the library factorisation (rocSOLVER through torch.linalg.cholesky_ex):
 // 3.5 ms per iteration at 1194 x 1194, a chain of ~60 small unblocked-panel launches.  Here, per block column of 32:
 //   panel   every workgroup factorises the 32 x 32 diagonal block redundantly in LDS (no extra launch, no dependency on
-//           another workgroup), then each THREAD solves one row below it against the block (row in registers, the block
-//           as LDS broadcasts);
+//           another workgroup), then solves 32 rows below it against the block, eight lanes per row;
 //   update  64 x 64 tiles of the trailing lower triangle, one workgroup each, panels staged in LDS.
 // The right-hand side rides along as row n of the matrix, so the forward substitution is part of the factorisation;
 // the back substitution is one workgroup (column blocks from the last to the first, 1024 threads on the updates).
+// Measured at 1194 x 1194 (200 keyframes): panel launches 38 x 29 us — 26 of them the 32 barrier-paced pivots of the
+// diagonal block (double-precision root and divisions on the critical path), whatever the number of rows behind it —
+// updates 38 x 14 us, back substitution 0.32 ms: 2.1 ms per solve against 3.5 ms for the library.
 // Parity: unpinned, like the rest of the bundle adjustment (the reference needs Eigen, absent here); held to an fp64
 // library solve in tests/test_ba.py.
 #include "lgu_common.hpp"
@@ -35,20 +37,38 @@ __global__ void chol_prepare_kernel(double* A, const double* __restrict__ b, dou
 // Row r of the working matrix: r < n is a row of A, r == n is the right-hand side.
 __device__ __forceinline__ double* chol_row(double* A, double* ext, int n, int r) { return r < n ? A + (size_t)r * n : ext; }
 
+// Sum over each group of 8 consecutive lanes (every lane of the group gets the total): three DPP steps on the two halves
+// of the double (xor 1, xor 2 inside quads; the half-row mirror pairs lane i with 7 - i of the other quad).
+__device__ __forceinline__ double chol_sum8(double v) {
+#define LGU_DPP_ADD(ctrl)                                                                     \
+  {                                                                                           \
+    const long long bits = __builtin_bit_cast(long long, v);                                  \
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, ctrl, 0xf, 0xf, false);          \
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xf, 0xf, false);  \
+    v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);                    \
+  }
+  LGU_DPP_ADD(0xB1)   // quad_perm:[1,0,3,2]
+  LGU_DPP_ADD(0x4E)   // quad_perm:[2,3,0,1]
+  LGU_DPP_ADD(0x141)  // row_half_mirror
+#undef LGU_DPP_ADD
+  return v;
+}
+
+constexpr int CH_RPW = CH_T / 8;  // rows a panel workgroup solves: eight lanes per row
+
 __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext, double* stage, int* flag, int n, int k0) {
-  extern __shared__ double chol_smem[];
-  double (*D)[CH_NB + 1] = reinterpret_cast<double (*)[CH_NB + 1]>(chol_smem);               // [CH_NB][CH_NB + 1]
-  double* const dsq = chol_smem + CH_NB * (CH_NB + 1);                                        // [CH_NB] roots of the pivots
-  double (*Bs)[CH_T + 1] = reinterpret_cast<double (*)[CH_T + 1]>(dsq + CH_NB);                // [CH_NB][CH_T + 1]: column c of thread t's row 
+  __shared__ double D[CH_NB][CH_NB + 1];
+  __shared__ double dsq[CH_NB];
   const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
   const int t = threadIdx.x;
-  // this thread's row behind the block (r == n: the right-hand side), requested before the block is factorised.
-  // (Reading the rows cooperatively, 32 consecutive threads per row, and transposing through LDS was measured and is
-  // slower: 47 against 40 us per launch.)
-  const int r = k0 + w + blockIdx.x * CH_T + t;
+  // this lane's share of its row behind the block (r == n: the right-hand side): columns l, l + 8, l + 16, l + 24 — the
+  // eight lanes of a row read 64 contiguous bytes per load; requested before the block is factorised
+  const int l = t & 7;
+  const int r = k0 + w + blockIdx.x * CH_RPW + (t >> 3);
   double* const rp = r <= n ? chol_row(A, ext, n, r) + k0 : nullptr;
-  if (rp)
-    for (int j = 0; j < w; j++) Bs[j][t] = rp[j];
+  double x[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) x[a] = (rp && 8 * a + l < w) ? rp[8 * a + l] : 0.0;
   // diagonal block, lower triangle; padded to CH_NB with the identity
   for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) {
     const int i = idx / CH_NB, j = idx - i * CH_NB;
@@ -83,23 +103,29 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
   // block.  The update launch that follows copies it in.
   if (blockIdx.x == 0)
     for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) stage[idx] = D[idx / CH_NB][idx % CH_NB];
-  // rows behind the block: X L_kk^T = A_ik, one row per thread; the row lives in LDS (column-major over the threads:
-  // conflict-free), the block entries are broadcasts.  (With the row in registers the fully unrolled 32 x 32 solve made
-  // hipcc hold the whole block in registers too: 512 VGPRs and 600 spilled.)
-  if (!rp) return;
-  for (int j = 0; j < w; j++) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four independent chains: the LDS latency of one read per product is the cost
-    int p = 0;
-    for (; p + 4 <= j; p += 4) {
-      s0 += Bs[p][t] * D[j][p];
-      s1 += Bs[p + 1][t] * D[j][p + 1];
-      s2 += Bs[p + 2][t] * D[j][p + 2];
-      s3 += Bs[p + 3][t] * D[j][p + 3];
+  if (t < CH_NB) dsq[t] = 1.0 / D[t][t];  // reciprocal pivots for the row solve (one division per pivot instead of one per row and pivot)
+  __syncthreads();
+  // rows behind the block: X L_kk^T = A_ik by forward substitution, EIGHT LANES PER ROW: lane l holds x_l, x_{l+8}, x_{l+16},
+  // x_{l+24}; step j sums the products x_p L_jp (p < j) over the group with three DPP adds and the owner of column j takes
+  // x_j = (a_j - sum) * (1 / L_jj).  (One thread per row was a chain of 496 LDS round trips: 39 us per launch.)
+#pragma unroll
+  for (int j = 0; j < CH_NB; j++) {
+    constexpr int dummy = 0; (void)dummy;
+    const int aj = j >> 3, lj = j & 7;
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      if (a < aj) s += x[a] * D[j][8 * a + l];
+      else if (a == aj) s += (l < lj) ? x[a] * D[j][8 * a + l] : 0.0;
     }
-    for (; p < j; p++) s0 += Bs[p][t] * D[j][p];
-    const double v = (Bs[j][t] - ((s0 + s1) + (s2 + s3))) / D[j][j];
-    Bs[j][t] = v;
-    rp[j] = v;
+    s = chol_sum8(s);
+    const double v = (x[aj] - s) * dsq[j];
+    x[aj] = (l == lj) ? v : x[aj];
+  }
+  if (rp) {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+      if (8 * a + l < w) rp[8 * a + l] = x[a];
   }
 }
 
@@ -221,10 +247,8 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
   double* ext = work;
   int* flag = reinterpret_cast<int*>(work + n);
   double* stage = work + n + 2;
-  const size_t panel_lds = sizeof(double) * (CH_NB * (CH_NB + 1) + CH_NB + CH_NB * (CH_T + 1));
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -232,7 +256,7 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
   for (int k0 = 0; k0 < n; k0 += CH_NB) {
     const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
     const int rows = n + 1 - (k0 + w);  // rows behind the block, the right-hand side included
-    hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_T - 1) / CH_T), dim3(CH_T), panel_lds, st, A, ext, stage, flag, n, k0);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_RPW - 1) / CH_RPW), dim3(CH_T), 0, st, A, ext, stage, flag, n, k0);
     const int nt = (rows + CH_TILE - 1) / CH_TILE;
     hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(CH_T), 0, st, A, ext, stage, n, k0, w);
   }
