@@ -77,6 +77,8 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
     D[i][j] = v;
   }
   __syncthreads();
+  // (A one-barrier form — every thread keeps its entries and a running copy of their columns' pivots in registers — was
+  // built and measured: 36 against 29 us per launch; up to four root-and-divide sequences per thread on the critical path.)
   for (int j = 0; j < w; j++) {
     // every thread of column j takes the root of the pivot itself (no barrier between the pivot and the scaling)
     if (t >= j && t < w) {

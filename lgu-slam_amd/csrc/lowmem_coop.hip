@@ -292,7 +292,10 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
         }
         const int xlo = pk_lo(lo), ylo = pk_hi(lo), xhi = pk_lo(hi) + 1, yhi = pk_hi(hi) + 1;  // + 1: the right / bottom corners
         const bool any = pv && xhi > xlo && yhi > ylo;
-        const bool boxed = any && xhi - xlo < 16 && yhi - ylo < 16;
+        // a conversion that hit the int16 rails (coords beyond +-32767: points behind the camera) no longer says where the
+        // taps are: such a pixel takes the per-tap fallback, whose range checks work on the full integers
+        const bool sat = xlo <= -32768 || ylo <= -32768 || xhi >= 32767 || yhi >= 32767;
+        const bool boxed = any && !sat && xhi - xlo < 16 && yhi - ylo < 16;
         // what the sweep has to visit: the box clipped to the map
         const int cx0 = xlo > 0 ? xlo : 0, cy0 = ylo > 0 ? ylo : 0, cx1 = xhi < W2 ? xhi : W2 - 1, cy1 = yhi < H2 ? yhi : H2 - 1;
         const bool inmap = boxed && cx0 <= cx1 && cy0 <= cy1;
@@ -601,6 +604,9 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
                          int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, hipStream_t st) {
   if (env_int("LGU_LOWMEM_COOP", 1) == 0) return -1;
   if (L < 1 || L > CO_MAXL || radius < 1 || radius > 3 || S > 65535) return -1;
+  // a single zero-offset level (altcorr_forward; the r = 1 probe of AltCorrBlock) has little window to share and no
+  // offsets to wait for: the independent waves of the one-wave kernel serve it faster (probe: 18 against 25 us)
+  if (L == 1 && !offset[0] && env_int("LGU_LOWMEM_COOP_SINGLE", 0) == 0) return -1;
   uintptr_t al = reinterpret_cast<uintptr_t>(fmap1);
   for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(fmap2[l]);
   if ((al & 15) != 0) return -1;
