@@ -211,19 +211,46 @@ def _events():
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
-def time_blocks(step, steps, blocks, pre_block=None):
+NO_GRAPH = False  # --no-graph
+
+
+def capture_steps(step, first, count):
+    """`count` consecutive steps (launch indices first .. first + count - 1) captured into ONE HIP graph, or None when
+    capture is not possible.  The timed region then replays the graph: K launches back to back with no host code between
+    them, so `value` does not depend on how fast this box's host issues a ~50 us launch (the kernels, their order and
+    their inputs are exactly those of the direct loop)."""
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(count):
+                step(first + i)
+        g.replay()  # untimed: the first launch of a graph uploads it
+        torch.cuda.synchronize()
+        return g
+    except Exception as exc:  # pragma: no cover - depends on the runtime
+        sys.stderr.write("bench: HIP graph capture failed (%s); timing direct launches\n" % exc)
+        torch.cuda.synchronize()
+        return None
+
+
+def time_blocks(step, steps, blocks, pre_block=None, use_graph=True):
     """Device time per step (ms) of `blocks` blocks of `steps` back-to-back launches, HIP events on torch's current
     stream (the stream every launch goes to).  step(i) is given the global launch index.  Returns the list of per-block
-    averages; callers report the median."""
+    averages; callers report the median.  Without per-block state to restore (pre_block) the block is captured once into
+    a HIP graph and replayed, so that the events bracket device work only, not this host's launch rate."""
+    graph = capture_steps(step, 0, steps) if (use_graph and pre_block is None and not NO_GRAPH) else None
     res, n = [], 0
     for _ in range(blocks):
         if pre_block is not None:
             pre_block()
         e0, e1 = _events()
         e0.record()
-        for _ in range(steps):
-            step(n)
-            n += 1
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(steps):
+                step(n)
+                n += 1
         e1.record()
         e1.synchronize()
         res.append(e0.elapsed_time(e1) / steps)
@@ -354,12 +381,16 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
 
     for _ in range(args.warmup):
         plan(coords, out=out)
+    graph = None if args.no_graph else capture_steps(lambda i: plan(coords, out=out), 0, args.steps)
     barrier()
     ev0, ev1 = _events()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        plan(coords, out=out)
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            plan(coords, out=out)
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -570,11 +601,15 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the 'extra' figures (probe on, row-major operator path, "
                     "config 3, config 4, warm cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="issue the timed steps one by one from Python instead of replaying "
+                                                             "them from one HIP graph")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / process-group / timing / JSON logic with gloo on CPU and an "
                          "empty step (no kernel runs, the printed value is meaningless)")
     args = ap.parse_args()
+    global NO_GRAPH
+    NO_GRAPH = args.no_graph
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -633,12 +668,17 @@ def main():
         step(i)
     if args.probe:
         sets.restore_offsets()
+    # the K timed steps as one HIP graph (not with the stateful probe: its offsets are restored between blocks)
+    graph = None if (args.no_graph or args.probe) else capture_steps(step, args.warmup, args.steps)
     barrier()
     ev0, ev1 = _events()
     t0 = time.perf_counter()
     ev0.record()  # kernels are enqueued on torch's current stream, which these events time
-    for i in range(args.steps):
-        step(args.warmup + i)
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(args.steps):
+            step(args.warmup + i)
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -699,6 +739,8 @@ def main():
                                 "off (BASELINE.json's metric: the 4-level deformable sample alone; the production call with the "
                                 "level-1 probe fused in is extra.probe_on)",
                        "cache": cache_note,
+                       "launch": ("the K timed steps replayed from one HIP graph (same kernels, order and inputs as the direct loop)"
+                                  if graph is not None else "K direct launches from Python"),
                        "edges_per_gpu": E, "units_per_step_per_gpu": units, "sharding": "edges (no data-path collective)",
                        "variant": args.variant, "volumes": "N(0,1)" if args.randn_volumes else "fmap products + avg_pool pyramid",
                        "pyramid_layout": "4x8-tiled slices (CorrBlock's own storage; results bit-identical)" if tiled
