@@ -175,6 +175,26 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
                                const void* wpack, const float* bias, float* out, int E, int H, int W, int C, int Cout,
                                void* stream);
 
+/* The same heads through per-FRAME partial convolutions (csrc/offconv.hip).  The convolution is linear in its input
+ * cat(frame ii, frame jj): conv(cat(a, b)) = conv_A(a) + conv_B(b), a frame is source / target of ~10 edges each, and one
+ * AltCorrBlock serves every chunk of an update_lowmem pass (reference factor_graph.py:272-300): P_A[f] = conv_A(frames[f])
+ * + bias and P_B[f] = conv_B(frames[f]) are computed once per frame and kept, an edge's output is P_A[ii] + P_B[jj].
+ *   lgu_offset_heads_mark         claims, on the device, the frames of ii (half 0) / jj (half 1) whose partials are
+ *                                 missing: done (2, NF) int32 flags (0 = missing, set to 1), worklist (>= 2E ints)
+ *                                 receives frame * 2 + half per claimed frame, *count their number (zero before the first
+ *                                 call; reset by the combine).
+ *   lgu_offset_conv_worklist_h16  the partial convolutions of the worklist: wpack_a / wpack_b = the weight's two input halves
+ *                                 packed like wpack above (C input channels each, C % 64 == 0), bias added to P_A only;
+ *                                 PA, PB (NF, Cout, H, W) fp32; maxwork >= the worklist's possible length (sizes the grid).
+ *   lgu_offset_heads_combine_f32  out[e] = PA[ii[e]] + PB[jj[e]] over rows of n floats (n % 4 == 0); *count_reset = 0. */
+int lgu_offset_heads_mark(const long long* ii, const long long* jj, int E, int* done, int NF, int* worklist, int* count,
+                          void* stream);
+int lgu_offset_conv_worklist_h16(const void* frames, const void* frames_lo, const int* worklist, const int* count, int maxwork,
+                                 const void* wpack_a, const void* wpack_b, const float* bias_a, float* PA, float* PB, int H,
+                                 int W, int C, int Cout, void* stream);
+int lgu_offset_heads_combine_f32(const float* PA, const float* PB, const long long* ii, const long long* jj, float* out, int E,
+                                 int n, int* count_reset, void* stream);
+
 /* Post-processing of the learned sampling offsets (reference droid_slam/modules/corr.py:117-135 and :217-235 with
  * per_Corr_Normalization, gaussianMask_cuda.py:26-33) in one pass:
  *   o0 (E,C,H,W), o1 (E,C,Hl,Wl): the outputs of the two offset convolutions (o1 still at the pooled resolution; the

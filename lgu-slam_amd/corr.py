@@ -10,6 +10,8 @@ fused launch for the whole pyramid (ops.defcorr_pyramid_forward) instead of four
 launches and a torch.cat, and never reads the offset tensors of levels that are zero by
 construction.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -60,6 +62,7 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
     return (x - mean) / std
 
 
+HEAD_CACHE = os.environ.get("LGU_HEAD_CACHE", "1") != "0"   # debug / A-B only: 0 = one convolution per edge and call
 FUSED_OFFSETS = True   # False: the reference-shaped torch composition below also in inference (A/B and tests)
 
 
@@ -433,11 +436,27 @@ class AltCorrBlock:
                 self._pooled = (pooled * 4.0,)
         iic, jjc = ii.contiguous(), jj.contiguous()
         try:
-            o0 = ops.offset_conv_frames(frames0, iic, jjc, self._ofs_packed)
-            if len(self._pooled) == 2:
-                o1_low = ops.offset_conv_frames(self._pooled[0], iic, jjc, self._res_packed, frames_lo=self._pooled[1])
+            if HEAD_CACHE and res_fast and C % 64 == 0:
+                # per-frame partial convolutions, kept for the life of this block (ops.OffsetHeadCache): the heads are
+                # linear in cat(frame ii, frame jj), a frame is source / target of ~10 edges each and the block serves
+                # every chunk of an update_lowmem pass, so each frame is convolved once and an edge costs a sum
+                if getattr(self, "_head_key", None) != key:
+                    self._head0 = ops.OffsetHeadCache(frames0, ops.pack_offset_conv_parts(conv.weight, conv.bias))
+                    self._head1 = ops.OffsetHeadCache(self._pooled[0], ops.pack_offset_conv_parts(res.weight, res.bias),
+                                                      frames_lo=self._pooled[1])
+                    self._head_key = key
+                E = iic.shape[0]
+                work = self._head0.mark(iic, jjc)   # one claim pass for both heads: they need the same frames
+                self._head0.convolve(work, E)
+                self._head1.convolve(work, E)
+                o0 = self._head0.combine(iic, jjc)
+                o1_low = self._head1.combine(iic, jjc, reset=work[1])
             else:
-                o1_low = res(torch.cat((self._pooled[0][ii], self._pooled[0][jj]), dim=1))
+                o0 = ops.offset_conv_frames(frames0, iic, jjc, self._ofs_packed)
+                if len(self._pooled) == 2:
+                    o1_low = ops.offset_conv_frames(self._pooled[0], iic, jjc, self._res_packed, frames_lo=self._pooled[1])
+                else:
+                    o1_low = res(torch.cat((self._pooled[0][ii], self._pooled[0][jj]), dim=1))
         except _lib.UnsupportedShape:
             return False
         self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels)

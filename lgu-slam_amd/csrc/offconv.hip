@@ -49,6 +49,15 @@ struct OffConvParams {
   const float* bias;       // (Cout)
   float* out;              // (E, Cout, H, W)
   int E, H, W, C, Cout, KS;
+  int ksh;                 // K steps per tap that read frame ii[e]; the rest read jj[e] (two-source form: KS / 2)
+  // Worklist form (per-frame partial convolutions, lgu_offset_conv_worklist_h16): "edge" k is entry k of the worklist —
+  // frame worklist[k] >> 1, input half worklist[k] & 1 — as long as k < *wcount; the single source is that frame, the
+  // weights / bias / output buffer those of its half, and the output row is the FRAME.
+  const int* worklist;
+  const int* wcount;
+  const _Float16* wpack_b;
+  const float* bias_b;
+  float* out_b;
 };
 
 // LO: the input has two half parts (e.g. 2 x 2 averages of half values, which need up to 24 bits): x = hi + lo and
@@ -69,12 +78,25 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
   char* const wbuf = reinterpret_cast<char*>(oc_smem);
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int e = blockIdx.y;
+  int e = blockIdx.y;
   const int HW = p.H * p.W;
   const int lr = lane & 15, kg = lane >> 4;
   const size_t fstride = (size_t)HW * p.C;
-  const size_t o1 = (size_t)p.ii[e] * fstride, o2 = (size_t)p.jj[e] * fstride;
-  const int ksh = p.KS >> 1;  // K steps per frame
+  size_t o1, o2;
+  const _Float16* wpack = p.wpack;
+  const float* bias = p.bias;
+  float* outp = p.out;
+  if (p.worklist) {
+    if ((int)blockIdx.y >= *p.wcount) return;  // workgroup-uniform
+    const int entry = p.worklist[blockIdx.y];
+    e = entry >> 1;
+    o1 = o2 = (size_t)e * fstride;
+    if (entry & 1) { wpack = p.wpack_b; bias = p.bias_b; outp = p.out_b; }
+  } else {
+    o1 = (size_t)p.ii[e] * fstride;
+    o2 = (size_t)p.jj[e] * fstride;
+  }
+  const int ksh = p.ksh;  // K steps per tap of the first frame
 
   // this lane's A-row pixel in each of the wave's tiles
   int py[MT], px[MT];
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
   // (slot = ring slot to fill, s = chunk to read: they differ only past the last step, where the pipeline keeps issuing
   // so that every step carries the same number of operations; those fills land in a slot nobody reads any more)
   auto stage = [&](int slot, int s) {
-    const char* src = reinterpret_cast<const char*>(p.wpack) + (size_t)s * OC_CHUNK + (size_t)w * 1024 + lane * 16;
+    const char* src = reinterpret_cast<const char*>(wpack) + (size_t)s * OC_CHUNK + (size_t)w * 1024 + lane * 16;
     char* dst = wbuf + slot * OC_CHUNK + w * 1024;  // wave-uniform; the DMA adds lane * 16
     // four pieces per wave, branch-free: waves 2, 3 have only three (14 KiB = 3.5 x 4 KiB) and repeat their last one —
     // the same bytes to the same place.  (A branch around a DMA makes the compiler's wait-count pass lose the counts and
@@ -179,8 +201,8 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
     for (int n = 0; n < OC_NT; n++) {
       const int ch = n * 16 + lr;
       if (ch >= p.Cout || pix0 >= HW) continue;
-      const float b = p.bias[ch];
-      float* dst = p.out + ((size_t)e * p.Cout + ch) * HW + pix0;
+      const float b = bias ? bias[ch] : 0.f;
+      float* dst = outp + ((size_t)e * p.Cout + ch) * HW + pix0;
       const oc_f32x4 v = acc[t][n];
       if (pix0 + 3 < HW && (HW & 3) == 0) {
         *reinterpret_cast<float4*>(dst) = make_float4(v[0] + b, v[1] + b, v[2] + b, v[3] + b);
@@ -191,6 +213,40 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
       }
     }
   }
+}
+
+// ---- per-frame partial convolutions, cached across the calls of one AltCorrBlock ----------------------------------
+// The offset heads are linear in their input cat(frame ii, frame jj): conv(cat(a, b)) = conv_A(a) + conv_B(b).  A frame is
+// the source of ~10 edges and the target of ~10 more, and one AltCorrBlock serves every chunk of an update_lowmem pass
+// (reference factor_graph.py:272-300), so the partial results P_A[f] (+ bias) and P_B[f] are computed once per frame and
+// pass, and an edge's head output is P_A[ii] + P_B[jj]: 200 frame convolutions instead of 1970 edge convolutions for the
+// global BA of BASELINE config 5.  Which frames are still missing is decided on the device (no host round trip):
+//   mark     every (edge, half) entry claims its frame with an atomic on the frame's flag; winners append the frame to
+//            the worklist;
+//   conv     offconv_frames_kernel in worklist form (grid sized for the worst case, surplus workgroups leave at once);
+//   combine  out[e] = P_A[ii[e]] + P_B[jj[e]] (fixed order: bit-reproducible) and reset of the worklist counter.
+__global__ void offconv_mark_kernel(const long long* __restrict__ ii, const long long* __restrict__ jj, int E, int* done,
+                                    int NF, int* worklist, int* count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * E) return;
+  const int half = t >= E, e = half ? t - E : t;
+  const long long f = half ? jj[e] : ii[e];
+  if (f < 0 || f >= NF) return;
+  if (atomicCAS(&done[half * NF + (int)f], 0, 1) == 0) worklist[atomicAdd(count, 1)] = (int)f * 2 + half;
+}
+
+__global__ void offconv_combine_kernel(const float4* __restrict__ PA, const float4* __restrict__ PB,
+                                       const long long* __restrict__ ii, const long long* __restrict__ jj,
+                                       float4* __restrict__ out, int n4, int* count_reset) {
+  const int e = blockIdx.y;
+  const float4* a = PA + (size_t)ii[e] * n4;
+  const float4* b = PB + (size_t)jj[e] * n4;
+  float4* o = out + (size_t)e * n4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const float4 x = a[i], y = b[i];
+    o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  if (count_reset && e == 0 && blockIdx.x == 0 && threadIdx.x == 0) *count_reset = 0;
 }
 
 }  // namespace lgu
@@ -212,6 +268,7 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
   p.frames = static_cast<const _Float16*>(frames); p.frames_lo = static_cast<const _Float16*>(frames_lo); p.ii = ii; p.jj = jj;
   p.wpack = static_cast<const _Float16*>(wpack); p.bias = bias; p.out = out;
   p.E = E; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.KS = 2 * C / 32;
+  p.ksh = p.KS / 2; p.worklist = nullptr; p.wcount = nullptr; p.wpack_b = nullptr; p.bias_b = nullptr; p.out_b = nullptr;
   // pixel tiles per wave: 2 (128 pixels per workgroup) unless that leaves fewer than two workgroups per CU
   const int mt = ((H * W + 127) / 128) * E >= 512 ? 2 : 1;
   const dim3 grid((H * W + 64 * mt - 1) / (64 * mt), E);
@@ -221,6 +278,69 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
   if (frames_lo) { if (mt == 2) LGU_OC(true, 2); else LGU_OC(true, 1); }
   else { if (mt == 2) LGU_OC(false, 2); else LGU_OC(false, 1); }
 #undef LGU_OC
+  return launch_status();
+}
+
+/* Claims the frames of ii (half 0) / jj (half 1) whose partial convolutions are still missing: done (2, NF) int32 flags
+ * (0 = missing; set to 1 here), worklist (>= 2E ints) gets frame * 2 + half per claimed frame, *count their number (the
+ * caller zero-initialises it once; lgu_offset_heads_combine_f32 resets it). */
+int lgu_offset_heads_mark(const long long* ii, const long long* jj, int E, int* done, int NF, int* worklist, int* count,
+                          void* stream) {
+  using namespace lgu;
+  if (!ii || !jj || !done || !worklist || !count || E < 0 || NF < 1) return LGU_E_BADARG;
+  if (E == 0) return LGU_OK;
+  hipLaunchKernelGGL(offconv_mark_kernel, dim3((2 * E + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ii, jj, E,
+                     done, NF, worklist, count);
+  return launch_status();
+}
+
+/* Partial convolutions of the worklist's frames: P_A[f] = conv_A(frames[f]) + bias for entries of half 0, P_B[f] =
+ * conv_B(frames[f]) for half 1 (wpack_a / wpack_b: pack_offset_conv of the two input halves of the weight, C input
+ * channels each; C % 64 == 0).  PA, PB (NF, Cout, H, W) fp32, rows of unlisted frames untouched.  maxwork >= the
+ * worklist's length bound (2E): the grid is sized with it. */
+int lgu_offset_conv_worklist_h16(const void* frames, const void* frames_lo, const int* worklist, const int* count, int maxwork,
+                                 const void* wpack_a, const void* wpack_b, const float* bias_a, float* PA, float* PB, int H,
+                                 int W, int C, int Cout, void* stream) {
+  using namespace lgu;
+  if (!frames || !worklist || !count || !wpack_a || !wpack_b || !bias_a || !PA || !PB) return LGU_E_BADARG;
+  if (maxwork < 0 || H < 1 || W < 1 || C < 1 || Cout < 1) return LGU_E_BADARG;
+  if (C % 64 != 0 || Cout > OC_NT * 16 || maxwork > 65535 ||
+      ((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(frames_lo) | reinterpret_cast<uintptr_t>(wpack_a) |
+        reinterpret_cast<uintptr_t>(wpack_b) | reinterpret_cast<uintptr_t>(PA) | reinterpret_cast<uintptr_t>(PB)) & 15) != 0)
+    return LGU_E_UNSUPPORTED;
+  if (maxwork == 0) return LGU_OK;
+  OffConvParams p;
+  p.frames = static_cast<const _Float16*>(frames); p.frames_lo = static_cast<const _Float16*>(frames_lo); p.ii = nullptr; p.jj = nullptr;
+  p.wpack = static_cast<const _Float16*>(wpack_a); p.bias = bias_a; p.out = PA;
+  p.wpack_b = static_cast<const _Float16*>(wpack_b); p.bias_b = nullptr; p.out_b = PB;
+  p.E = maxwork; p.H = H; p.W = W; p.C = C; p.Cout = Cout; p.KS = C / 32; p.ksh = p.KS;
+  p.worklist = worklist; p.wcount = count;
+  const int mt = ((H * W + 127) / 128) * maxwork >= 512 ? 2 : 1;
+  const dim3 grid((H * W + 64 * mt - 1) / (64 * mt), maxwork);
+  const size_t lds = (size_t)OC_RING * OC_CHUNK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LGU_OC(LOV, MTV) hipLaunchKernelGGL((offconv_frames_kernel<LOV, MTV>), grid, dim3(OC_WAVES * kWave), lds, st, p)
+  if (frames_lo) { if (mt == 2) LGU_OC(true, 2); else LGU_OC(true, 1); }
+  else { if (mt == 2) LGU_OC(false, 2); else LGU_OC(false, 1); }
+#undef LGU_OC
+  return launch_status();
+}
+
+/* out[e] = PA[ii[e]] + PB[jj[e]], rows of n floats (n % 4 == 0, 16-byte aligned buffers); *count_reset = 0 if given. */
+int lgu_offset_heads_combine_f32(const float* PA, const float* PB, const long long* ii, const long long* jj, float* out, int E,
+                                 int n, int* count_reset, void* stream) {
+  using namespace lgu;
+  if (!PA || !PB || !ii || !jj || !out || E < 0 || n < 4) return LGU_E_BADARG;
+  if (n % 4 != 0 || E > 65535 ||
+      ((reinterpret_cast<uintptr_t>(PA) | reinterpret_cast<uintptr_t>(PB) | reinterpret_cast<uintptr_t>(out)) & 15) != 0)
+    return LGU_E_UNSUPPORTED;
+  if (E == 0) return LGU_OK;
+  const int n4 = n / 4;
+  int bx = (n4 + 255) / 256;
+  bx = bx > 64 ? 64 : bx;
+  hipLaunchKernelGGL(offconv_combine_kernel, dim3(bx, E), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(PA), reinterpret_cast<const float4*>(PB), ii, jj, reinterpret_cast<float4*>(out), n4,
+                     count_reset);
   return launch_status();
 }
 

@@ -584,6 +584,86 @@ def pack_offset_conv(weight, bias, scale=4.0):
     return wpack, bias.detach().float().contiguous(), Cout, C2 // 2
 
 
+def pack_offset_conv_parts(weight, bias, scale=4.0):
+    """The two input halves of a Conv2d(2C, Cout, 3, padding=1) packed separately (pack_offset_conv of weight[:, :C] and
+    weight[:, C:]) for the per-frame partial convolutions of OffsetHeadCache.  Returns (wpack_a, wpack_b, bias, Cout, C)."""
+    Cout, C2 = weight.shape[:2]
+    C = C2 // 2
+    if C % 64 != 0:
+        raise _lib.UnsupportedShape("pack_offset_conv_parts: C must be a multiple of 64")
+    wa = pack_offset_conv(weight[:, :C], bias, scale)
+    wb = pack_offset_conv(weight[:, C:], bias, scale)
+    return wa[0], wb[0], wa[1], Cout, C
+
+
+class OffsetHeadCache:
+    """One offset head of AltCorrBlock (a 3x3 convolution of cat(frames[ii], frames[jj])) through per-frame partial
+    convolutions kept for the life of the block: P_A[f] + P_B[f'] for an edge (f, f').  Frames whose partials are missing
+    are found and convolved on the device (lgu_offset_heads_mark / lgu_offset_conv_worklist_h16), so a call costs no host
+    round trip; every later chunk that meets a frame again pays only the sum."""
+
+    def __init__(self, frames, parts, frames_lo=None):
+        wa, wb, bias, Cout, C = parts
+        _check_dtype(frames, "frames", torch.float16)
+        NF, H, W, Cf = frames.shape
+        if Cf != C or not frames.is_contiguous():
+            raise RuntimeError("OffsetHeadCache: frames must be contiguous (NF,H,W,%d)" % C)
+        if (Cout * H * W) % 4 != 0:
+            raise _lib.UnsupportedShape("OffsetHeadCache: Cout*H*W must be a multiple of 4")
+        self.frames, self.frames_lo, self.parts = frames, frames_lo, parts
+        self.NF, self.H, self.W, self.C, self.Cout = NF, H, W, C, Cout
+        dev = frames.device
+        self.PA = torch.empty((NF, Cout, H, W), dtype=torch.float32, device=dev)
+        self.PB = torch.empty((NF, Cout, H, W), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((2, NF), dtype=torch.int32, device=dev)
+        self.count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.worklist = None
+
+    def mark(self, ii, jj):
+        """Device-side claim of the frames of ii / jj that have no partials yet -> (worklist, count) tensors.  Two heads
+        over the same frames (AltCorrBlock's full-resolution and residual head) share ONE mark pass: the flags of the
+        cache that marks stand for both."""
+        _check_dtype(ii, "ii", torch.int64)
+        _check_dtype(jj, "jj", torch.int64)
+        E = ii.shape[0]
+        if self.worklist is None or self.worklist.numel() < 2 * E:
+            self.worklist = torch.empty(max(2 * E, 64), dtype=torch.int32, device=self.frames.device)
+        if E:
+            with torch.cuda.device(self.frames.device):
+                _lib.check(_lib.load().lgu_offset_heads_mark(_ptr(ii), _ptr(jj), E, _ptr(self.done), self.NF, _ptr(self.worklist),
+                                                             _ptr(self.count), _stream(self.frames)), "offset_heads_mark")
+        return self.worklist, self.count
+
+    def convolve(self, work, E):
+        """Partial convolutions of the frames on the worklist `work` = (worklist, count) of a mark pass over E edges."""
+        if E == 0:
+            return
+        wa, wb, bias, Cout, C = self.parts
+        wl, cnt = work
+        with torch.cuda.device(self.frames.device):
+            _lib.check(_lib.load().lgu_offset_conv_worklist_h16(
+                _ptr(self.frames), _ptr(self.frames_lo) if self.frames_lo is not None else None, _ptr(wl), _ptr(cnt), 2 * E, _ptr(wa),
+                _ptr(wb), _ptr(bias), _ptr(self.PA), _ptr(self.PB), self.H, self.W, C, Cout, _stream(self.frames)), "offset_conv_worklist")
+
+    def combine(self, ii, jj, reset=None):
+        """(E, Cout, H, W) fp32 = P_A[ii] + P_B[jj]; reset: the count tensor of the mark pass, zeroed by the LAST combine
+        that follows it."""
+        E = ii.shape[0]
+        out = torch.empty((E, self.Cout, self.H, self.W), dtype=torch.float32, device=self.frames.device)
+        if E:
+            with torch.cuda.device(self.frames.device):
+                _lib.check(_lib.load().lgu_offset_heads_combine_f32(_ptr(self.PA), _ptr(self.PB), _ptr(ii), _ptr(jj), _ptr(out), E,
+                                                                    self.Cout * self.H * self.W, _ptr(reset) if reset is not None else None,
+                                                                    _stream(self.frames)), "offset_heads_combine")
+        return out
+
+    def __call__(self, ii, jj):
+        """One head on its own: mark, convolve what is missing, sum."""
+        work = self.mark(ii, jj)
+        self.convolve(work, ii.shape[0])
+        return self.combine(ii, jj, reset=work[1])
+
+
 def offset_conv_frames(frames, ii, jj, packed, frames_lo=None):
     """ofsMap(cat(frames[ii] * 4, frames[jj] * 4).float()) of AltCorrBlock.corr_fn (reference corr.py:174-189, :220)
     without materialising its input: frames (NF,H,W,C) half channel-last, ii / jj (E) int64, packed from

@@ -1677,3 +1677,75 @@ def test_lowmem_coop_kernel_scheduling_modes_and_the_one_wave_kernel(lgu, oracle
                                             host(coords[b:b + 1] / 2 ** l), o_np, radius)
             got = host(default[b:b + 1, :, l * 49:(l + 1) * 49]).reshape(want.shape)
             assert np.abs(got - want).max() <= 1e-5, (b, l)
+
+
+def test_offset_head_cache_equals_the_per_edge_convolution(lgu):
+    """ops.OffsetHeadCache (per-frame partial convolutions P_A[ii] + P_B[jj], found and convolved on the device, kept across
+    calls) against ops.offset_conv_frames (one convolution per edge and call) and an fp64 evaluation of the reference
+    expression ofsMap(cat(frames[ii] * 4, frames[jj] * 4).float()) (corr.py:174-189): same products, fp32 sums in another
+    order.  Three calls over overlapping frame sets: the second and third meet frames whose partials exist (their flags
+    are set, nothing is convolved twice) and frames that are new; the worklist counter is back at zero after every call.
+    Also the two-part input of the residual head and a frame set with duplicates inside one call."""
+    torch.manual_seed(5)
+    NF, H, W, C, Cout = 9, 12, 20, 128, 98
+    frames = (torch.randn(NF, H, W, C, device="cuda") * 0.125).half().contiguous()
+    conv = torch.nn.Conv2d(2 * C, Cout, 3, padding=1).cuda()
+    packed = lgu.ops.pack_offset_conv(conv.weight, conv.bias)
+    cache = lgu.ops.OffsetHeadCache(frames, lgu.ops.pack_offset_conv_parts(conv.weight, conv.bias))
+    calls = [([0, 0, 1, 2, 2], [1, 2, 0, 3, 1]), ([2, 3, 3, 4], [4, 2, 5, 3]), ([8, 0, 7], [0, 8, 7])]
+    seen_a, seen_b = set(), set()
+    for ii_l, jj_l in calls:
+        ii, jj = torch.tensor(ii_l, device="cuda"), torch.tensor(jj_l, device="cuda")
+        got = cache(ii, jj)
+        want = lgu.ops.offset_conv_frames(frames, ii, jj, packed)
+        x = torch.cat((frames[ii].double() * 4, frames[jj].double() * 4), dim=-1).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x, conv.weight.double(), conv.bias.double(), padding=1)
+        scale = float(ref.abs().max())
+        assert float((got - want).abs().max()) <= 2e-6 * scale
+        assert float((got.double() - ref).abs().max()) <= 5e-6 * scale
+        seen_a |= set(ii_l); seen_b |= set(jj_l)
+        done = cache.done.cpu().numpy()
+        assert set(np.nonzero(done[0])[0]) == seen_a and set(np.nonzero(done[1])[0]) == seen_b
+        assert int(cache.count.item()) == 0
+    # the residual head's form: input in two half parts (2 x 2 averages need up to 24 bits)
+    xf = torch.randn(NF, H, W, C, device="cuda") * 0.125
+    hi = xf.half()
+    lo = (xf - hi.float()).half()
+    cache2 = lgu.ops.OffsetHeadCache(hi.contiguous(), lgu.ops.pack_offset_conv_parts(conv.weight, conv.bias), frames_lo=lo.contiguous())
+    ii, jj = torch.tensor([1, 1, 6], device="cuda"), torch.tensor([6, 1, 1], device="cuda")
+    got = cache2(ii, jj)
+    want = lgu.ops.offset_conv_frames(hi.contiguous(), ii, jj, packed, frames_lo=lo.contiguous())
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_altcorrblock_head_cache_on_and_off(lgu, monkeypatch):
+    """AltCorrBlock with the per-frame head cache (default) and without (corr.HEAD_CACHE = False): two chunks of a graph
+    whose frames overlap give the same lookup (offsets equal to fp32 summation order; the lookup is continuous in them
+    away from integer sample positions, so it is compared loosely) and the same offsets closely."""
+    torch.manual_seed(12)
+    N, C, H, W = 6, 128, 16, 24
+    fmaps = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    with torch.no_grad():
+        for m in (ofsMap, ofsRes):
+            m.weight.mul_(0.3)
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    chunks = [(torch.tensor([0, 0, 1, 1], device="cuda"), torch.tensor([1, 2, 0, 2], device="cuda")),
+              (torch.tensor([2, 2, 3], device="cuda"), torch.tensor([1, 3, 2], device="cuda"))]
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(lgu.corr, "HEAD_CACHE", flag)
+        blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        res = []
+        with torch.no_grad():
+            for ii, jj in chunks:
+                coords = (torch.stack([xs, ys], -1)[None, None] + 1.5 * torch.randn(1, ii.numel(), H, W, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))).contiguous()
+                c = blk(coords, ii, jj)
+                res.append((c.clone(), [o.clone() for o in blk.offset[:2]]))
+        assert hasattr(blk, "_head0") == flag
+        outs[flag] = res
+    for (ca, oa), (cb, ob) in zip(outs[True], outs[False]):
+        for x, y in zip(oa, ob):
+            assert float((x - y).abs().max()) <= 2e-5
+        assert float((ca - cb).abs().mean()) <= 1e-4
