@@ -482,10 +482,20 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
         iis, jjs = ii[idx], jj[idx]
         return jjs + (iis == jjs).long()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    phase = {"lookups": [], "exchange": [], "ba": []}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    phase = {"corr_block": [], "lookups": [], "exchange": [], "ba": []}
+    # The reference builds ONE AltCorrBlock per update_lowmem call and runs `steps = 8` iterations over it
+    # (factor_graph.py:256-265).  Per-call state — the feature pyramid, its chunk-planar / pooled forms and the per-frame
+    # partial convolutions of the offset heads (ops.OffsetHeadCache) — is therefore rebuilt every CALL_STEPS-th iteration,
+    # INSIDE the timed region: a step carries an eighth of it on average (phase "corr_block" = mean over the timed steps).
+    CALL_STEPS = 8
+    it_no = [0]
 
     def step(record):
+        ev[4].record()
+        if it_no[0] % CALL_STEPS == 0:
+            sac.block = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        it_no[0] += 1
         ev[0].record()
         local = sh.run_chunks(edges, ii, chunk_fn)
         ev[1].record()
@@ -501,6 +511,7 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
             ev[3].synchronize()
             for k, name in enumerate(("lookups", "exchange", "ba")):
                 phase[name].append(ev[k].elapsed_time(ev[k + 1]))
+            phase["corr_block"].append(ev[4].elapsed_time(ev[0]))
 
     def barrier():
         if use_dist:
@@ -517,11 +528,12 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
     wall = time.perf_counter() - t0
     agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and world > 1 else True
     if use_dist:
-        t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))],
+                         device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ph = float(t[0]), [float(x) for x in t[1:]]
     else:
-        ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")]
+        ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))]
     if rank == 0:
         units = E * H * W
         emit({"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4; global BA step)",
@@ -534,7 +546,12 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                          "edges_total": E, "edges_this_rank": int(edges.counts[rank]), "chunks_this_rank": len(edges.my_chunks),
                          "units_per_step": units, "update_operator": "stand-in (out of scope)",
                          "ba": "lgu_slam_amd.ba (experimental: parity unpinned)"},
-              "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2]},
+              "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2],
+                                           "corr_block_per_step": ph[3]},
+              "phases_note": "lookups / exchange / ba: medians over the timed steps; corr_block_per_step: MEAN over the timed steps of "
+                             "the AltCorrBlock construction (pyramid) that every %d-th iteration starts with, as one update_lowmem "
+                             "call = one block + 8 iterations in the reference; the first iteration over a new block also pays the "
+                             "per-frame partial convolutions of the offset heads inside its lookups" % CALL_STEPS,
               "replicas_agree": agree,
               "roofline": None, "cpu_baseline": None})
     if use_dist:

@@ -17,7 +17,7 @@ timeout -k 10 300 python __graft_entry__.py smoke 2>&1 | tail -1 || exit 1
 timeout -k 10 500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 cut -c1-1500 gpurun_out/bench.json
 timeout -k 10 300 python bench.py --workload lowmem --edges 16 > gpurun_out/bench_lowmem.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-timeout -k 10 300 python bench.py --workload backend --steps 10 --warmup 2 > gpurun_out/bench_backend.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --workload backend --steps 16 --warmup 8 > gpurun_out/bench_backend.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/ab_cold.py 0,7,6 6 tiled,rowmajor 0,1 > gpurun_out/ab_final.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/ab_final.jsonl
 timeout -k 10 300 python tools/ab_lowmem.py 1,1:c,2:c > gpurun_out/ab_lowmem.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
