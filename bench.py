@@ -221,7 +221,9 @@ def capture_steps(step, first, count):
     their inputs are exactly those of the direct loop)."""
     try:
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: calls of other threads (RCCL's watchdog polling its events under torchrun) must neither fail nor
+        # invalidate this capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for i in range(count):
                 step(first + i)
         g.replay()  # untimed: the first launch of a graph uploads it

@@ -467,16 +467,18 @@ class AltCorrBlock:
         rd = 2 * self.radius + 1
         coords = coords.permute(0, 1, 4, 2, 3, 5)
 
-        f1 = self.pyramid[0][:, ii]
-        f1 = f1.reshape((B * N,) + f1.shape[2:])
+        def source_maps():   # the per-edge gather of the source frames: only the per-level operators below need it
+            f = self.pyramid[0][:, ii]
+            return f.reshape((B * N,) + f.shape[2:])
 
         def make_feats():
             # offsets come from the un-scaled level-0 maps (reference corr.py:177-189)
             # (standard NCHW strides: the cat of permuted views would come out channel-last, which sends the fp32
             # convolutions below to MIOpen's NHWC implicit-GEMM kernels — 0.89 ms against 0.48 ms for the NCHW ones)
+            f1_0 = source_maps()
             f2_0 = self.pyramid[0][:, jj]
             f2_0 = f2_0.reshape((B * N,) + f2_0.shape[2:])
-            return torch.cat(((f1 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
+            return torch.cat(((f1_0 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
                 .contiguous(memory_format=torch.contiguous_format)
 
         feats = None
@@ -489,8 +491,7 @@ class AltCorrBlock:
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
         # operators take exact half products, accumulate in fp32 and equal the reference's `.float()`
         # call sites up to fp32 summation order (<= 1e-5).
-        mixed = f1.dtype == torch.float16
-        f1 = f1.contiguous() if mixed else f1.float().contiguous()
+        mixed = self.pyramid[0].dtype == torch.float16
         if S == 1 and B == 1 and self.num_levels >= 2 and ii.dtype == torch.int64 and jj.dtype == torch.int64:
             # one sample per pixel (the SLAM system's case): the level-1 probe and then ALL levels in one launch each,
             # written straight into the concatenated tensor (ops.LowmemPyramidPlan).  Both read the frame buffers in
@@ -524,6 +525,8 @@ class AltCorrBlock:
                 self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats if feats is not None else make_feats(),
                                                   self.num_levels)
         out = []
+        f1 = source_maps()
+        f1 = f1.contiguous() if mixed else f1.float().contiguous()
         for i in range(self.num_levels):
             f2 = self.pyramid[i][:, jj]
             f2 = f2.reshape((B * N,) + f2.shape[2:])
