@@ -207,6 +207,12 @@ int lgu_offset_heads_combine_f32(const float* PA, const float* PB, const long lo
 long long lgu_offsets_finalize_scratch_bytes(int E);
 int lgu_offsets_finalize(const void* o0, const void* o1, float* out0, float* out1, void* scratch,
                          int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps, void* stream);
+/* The same with the uncertainty mask of AltCorrBlock.corr_fn (reference corr.py:203-207) folded in: probe (E, T, H, W) fp32,
+ * the T >= 2 plain level-1 samples of every pixel; out1 = level-1 offsets * sigmoid(unbiased variance over T) — bit for bit
+ * lgu_offsets_finalize followed by lgu_probe_mask_scale_f32, without the extra read-modify-write pass over out1. */
+int lgu_offsets_finalize_masked(const void* o0, const void* o1, const float* probe, int T, float* out0, float* out1,
+                                void* scratch, int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps,
+                                void* stream);
 
 /* Fused volume post-processing of CorrBlock.__init__ (reference droid_slam/gaussianMask_cuda.py:84-86
  * and droid_slam/modules/corr.py:79-86): in ONE pass over the raw all-pairs volume

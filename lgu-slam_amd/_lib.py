@@ -36,6 +36,7 @@ SIGNATURES = {
     "lgu_offset_conv_worklist_h16": [_vp] * 4 + [_int] + [_vp] * 5 + [_int] * 4 + [_vp],
     "lgu_offset_heads_combine_f32": [_vp] * 5 + [_int] * 2 + [_vp, _vp],
     "lgu_offsets_finalize": [_vp] * 5 + [_int] * 7 + [ctypes.c_float, _vp],
+    "lgu_offsets_finalize_masked": [_vp] * 3 + [_int] + [_vp] * 3 + [_int] * 7 + [ctypes.c_float, _vp],
     "lgu_volume_retile_f32": [_vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp],
     "lgu_lowmem_defsample_fwd_f32": [_vp] * 5 + [_int] * 9 + [_vp],
     "lgu_altcorr_fwd_f32": [_vp] * 4 + [_int] * 8 + [_vp],

@@ -91,14 +91,16 @@ def generate_offsets(ofsMap, ofs_residual, feats, num_levels):
     return finish_offsets(o0, o1_low, num_levels)
 
 
-def finish_offsets(o0, o1_low, num_levels):
-    """Everything of generate_offsets after the two convolutions: o0 (E,C,h,w), o1_low (E,C,h/2,w/2)."""
+def finish_offsets(o0, o1_low, num_levels, probe=None):
+    """Everything of generate_offsets after the two convolutions: o0 (E,C,h,w), o1_low (E,C,h/2,w/2).  probe (optional,
+    (E,1,T,h,w) fp32 plain level-1 samples): the level-1 offsets come back scaled by the uncertainty mask
+    sigmoid(var(probe)) of AltCorrBlock.corr_fn (corr.py:203-207)."""
     h, w = o0.shape[2:]
     if (FUSED_OFFSETS and num_levels >= 2 and o0.is_cuda and not (torch.is_grad_enabled() and o0.requires_grad)
             and o0.dtype in (torch.float32, torch.float16) and o1_low.dtype == o0.dtype):
         # inference: standardisation, tanh, residual mix, upsampling and the channel-last transposition in one pass
         try:
-            off0, off1 = ops.offsets_finalize(o0.contiguous(), o1_low.contiguous())
+            off0, off1 = ops.offsets_finalize(o0.contiguous(), o1_low.contiguous(), probe=probe)
             offsets = [off0, off1] + [_zero_offsets(off0, off0.shape[0])] * (num_levels - 2)
             return offsets[:num_levels], ([False, False] + [True] * (num_levels - 2))[:num_levels]
         except _lib.UnsupportedShape:
@@ -107,6 +109,10 @@ def finish_offsets(o0, o1_low, num_levels):
     o0 = torch.tanh(per_Corr_Normalization(o0, [1, 2, 3])) * 4
     o1 = (torch.tanh(per_Corr_Normalization(o1, [1, 2, 3])) * 4 + o0) / 2
     offsets = [o0.permute(0, 2, 3, 1), o1.permute(0, 2, 3, 1)]
+    if probe is not None:
+        E_, T_ = o0.shape[0], probe.numel() // (o0.shape[0] * h * w)
+        pr = probe.reshape(E_, T_, h, w).permute(0, 2, 3, 1)
+        offsets[1] = offsets[1] * torch.sigmoid(torch.var(pr, dim=3)).view(E_, h, w, 1)
     zero = [False, False]
     for _ in range(2, num_levels):
         offsets.append(torch.zeros_like(offsets[0]).detach())
@@ -394,7 +400,7 @@ class AltCorrBlock:
             self.pyramid.append(lvl.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
             lvl = F.avg_pool2d(lvl, 2, stride=2)
 
-    def _offsets_from_frames(self, B, ii, jj):
+    def _offsets_from_frames(self, B, ii, jj, probe=None):
         """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
         run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
         (E,256,H,W) tensor, fp32-accurate split-half weights).  The residual head's input, the 2 x 2 average of the
@@ -459,7 +465,7 @@ class AltCorrBlock:
                     o1_low = res(torch.cat((self._pooled[0][ii], self._pooled[0][jj]), dim=1))
         except _lib.UnsupportedShape:
             return False
-        self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels)
+        self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels, probe=probe)   # probe: level 1 comes back masked
         return True
 
     def corr_fn(self, coords, ii, jj):
@@ -481,22 +487,18 @@ class AltCorrBlock:
             return torch.cat(((f1_0 * 4.0).permute(0, 3, 1, 2), (f2_0 * 4.0).permute(0, 3, 1, 2)), dim=1).float() \
                 .contiguous(memory_format=torch.contiguous_format)
 
-        feats = None
-        if not self._offsets_from_frames(B, ii, jj):
-            feats = make_feats()
-            self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
-        else:
-            zero_level = self._zero_level
-
         # Features stored in half precision (as the SLAM system keeps them) stay half: the mixed
         # operators take exact half products, accumulate in fp32 and equal the reference's `.float()`
         # call sites up to fp32 summation order (<= 1e-5).
         mixed = self.pyramid[0].dtype == torch.float16
-        if S == 1 and B == 1 and self.num_levels >= 2 and ii.dtype == torch.int64 and jj.dtype == torch.int64:
-            # one sample per pixel (the SLAM system's case): the level-1 probe and then ALL levels in one launch each,
-            # written straight into the concatenated tensor (ops.LowmemPyramidPlan).  Both read the frame buffers in
-            # place at ii / jj (no per-edge gathers of the pyramid), half buffers stay half, and levels whose offsets
-            # are zero by construction read no offset tensor at all.
+        # One sample per pixel (the SLAM system's case): the level-1 probe and then ALL levels in one launch each, written
+        # straight into the concatenated tensor (ops.LowmemPyramidPlan).  Both read the frame buffers in place at ii / jj
+        # (no per-edge gathers of the pyramid), half buffers stay half, and levels whose offsets are zero by construction
+        # read no offset tensor at all.  The probe does not depend on the offsets, so it runs FIRST and the offset
+        # post-processing applies its uncertainty mask while it writes level 1 (no separate pass over that tensor).
+        fused_ok = S == 1 and B == 1 and self.num_levels >= 2 and ii.dtype == torch.int64 and jj.dtype == torch.int64
+        probe = frames = iic = jjc = c0 = None
+        if fused_ok:
             try:
                 frames = [p_[0].contiguous() for p_ in self.pyramid]            # (N,Hl,Wl,C): views of the stored pyramid
                 if not mixed:
@@ -509,19 +511,35 @@ class AltCorrBlock:
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
                 probe = ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1,
                                                          chunked=True)
-                o1 = self.offset[1]
-                if o1.dtype == torch.float32 and o1.is_contiguous() and not o1.requires_grad:
-                    ops.probe_mask_scale_(probe, o1)   # variance, sigmoid and the scaling in one pass, in place
-                else:
-                    probe = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
-                    mask = torch.sigmoid(torch.var(probe, dim=[3, 4])).view(B * N, H, W, 1)
-                    self.offset[1] = self.offset[1] * mask
+            except _lib.UnsupportedShape:
+                fused_ok, probe = False, None
+
+        feats = None
+        masked = False
+        if self._offsets_from_frames(B, ii, jj, probe=probe):
+            zero_level = self._zero_level
+            masked = probe is not None
+        else:
+            feats = make_feats()
+            self.offset, zero_level = generate_offsets(self.ofsMap, self.ofs_residual, feats, self.num_levels)
+
+        if fused_ok:
+            try:
+                if not masked:
+                    o1 = self.offset[1]
+                    if o1.dtype == torch.float32 and o1.is_contiguous() and not o1.requires_grad:
+                        ops.probe_mask_scale_(probe, o1)   # variance, sigmoid and the scaling in one pass, in place
+                    else:
+                        pr = probe.permute(0, 1, 3, 4, 2).contiguous().view(N, H, W, 3, 3)
+                        mask = torch.sigmoid(torch.var(pr, dim=[3, 4])).view(B * N, H, W, 1)
+                        self.offset[1] = self.offset[1] * mask
                 offs = [None if zero_level[i] else self.offset[i].contiguous().view(B * N, H, W, rd, rd, 2).float()
                         for i in range(self.num_levels)]
                 fused = ops.lowmem_pyramid_forward_mixed(frames[0], self._chunked, c0, offs, self.radius, ii=iic, jj=jjc, chunked=True)
                 return fused.view(B, N, -1, H, W).unsqueeze(-1)   # (1,E,L*rd*rd,H,W,S=1)
             except _lib.UnsupportedShape:
-                # channel counts / radii the matrix-core kernel does not serve: per-level operators below
+                # channel counts / radii the matrix-core kernel does not serve: per-level operators below, which apply the
+                # mask themselves to freshly generated offsets
                 self.offset, _ = generate_offsets(self.ofsMap, self.ofs_residual, feats if feats is not None else make_feats(),
                                                   self.num_levels)
         out = []

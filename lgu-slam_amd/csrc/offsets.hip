@@ -35,6 +35,8 @@ struct OffParams {
   float sy, sx;     // Hl / H, Wl / W as torch's nearest interpolate forms them
   float eps;
   int l1_f32;       // half inputs under autocast: the upsampling is promoted to fp32 there, so level 1 is fp32 arithmetic
+  const float* probe;  // optional (E, T, H, W): level 1 leaves scaled by sigmoid(var over the T probe samples) (corr.py:203-207)
+  int T;
 };
 
 template <bool HALF>
@@ -87,9 +89,28 @@ template <bool HALF>
 __global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffParams p) {
   extern __shared__ float of_sm[];  // [2][C][OF_TP + 1]
   __shared__ float stat[4];          // mean0, std0, mean1, std1
+  __shared__ float mask[OF_TP];      // probe form: the uncertainty mask of the tile's pixels
   const int e = blockIdx.y;
   const int HW = p.H * p.W, C = p.C;
   const int pix0 = blockIdx.x * OF_TP;
+  if (p.probe && threadIdx.x >= kWave && threadIdx.x < kWave + OF_TP) {  // the arithmetic of probe_mask_scale_kernel, on the second wave
+    const int pp_ = threadIdx.x - kWave;
+    float mk = 1.0f;
+    if (pix0 + pp_ < HW) {
+      const float* pr = p.probe + (size_t)e * p.T * HW + pix0 + pp_;
+      float mean = 0.0f;
+      for (int t = 0; t < p.T; t++) mean += pr[(size_t)t * HW];
+      mean /= (float)p.T;
+      float ss = 0.0f;
+      for (int t = 0; t < p.T; t++) {
+        const float d = pr[(size_t)t * HW] - mean;
+        ss += d * d;
+      }
+      const float var = ss / (float)(p.T - 1);
+      mk = 1.0f / (1.0f + expf(-var));
+    }
+    mask[pp_] = mk;
+  }
   if (threadIdx.x < 2) {  // fixed-order sum of the partials: deterministic
     double s = 0.0, q = 0.0;
     for (int k = 0; k < OF_CHUNKS; k++) {
@@ -145,7 +166,8 @@ __global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffP
   for (int idx = threadIdx.x; idx < npx * C; idx += OF_THREADS) {  // channel-last rows: one contiguous run per tile
     const int pp = idx / C, c = idx - pp * C;
     d0[idx] = t0[c * (OF_TP + 1) + pp];
-    d1[idx] = t1[c * (OF_TP + 1) + pp];
+    const float v1 = t1[c * (OF_TP + 1) + pp];
+    d1[idx] = p.probe ? v1 * mask[pp] : v1;   // = the stored value times the mask, as the separate in-place pass computes it
   }
 }
 
@@ -270,8 +292,25 @@ long long lgu_offsets_finalize_scratch_bytes(int E) {
   return E < 0 ? 0 : (long long)E * lgu::OF_CHUNKS * 4 * (long long)sizeof(double);
 }
 
+static int offsets_finalize_impl(const void* o0, const void* o1, const float* probe, int T, float* out0, float* out1, void* scratch,
+                                 int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps, void* stream);
+
 int lgu_offsets_finalize(const void* o0, const void* o1, float* out0, float* out1, void* scratch, int E, int C, int H,
                          int W, int Hl, int Wl, int is_half, float eps, void* stream) {
+  return offsets_finalize_impl(o0, o1, nullptr, 0, out0, out1, scratch, E, C, H, W, Hl, Wl, is_half, eps, stream);
+}
+
+/* lgu_offsets_finalize with the uncertainty mask of AltCorrBlock.corr_fn (reference corr.py:203-207) folded in: probe (E, T,
+ * H, W) fp32 holds the T >= 2 plain level-1 samples per pixel; out1 = level-1 offsets * sigmoid(unbiased var over T) — bit for
+ * bit what lgu_offsets_finalize followed by lgu_probe_mask_scale_f32 leaves there, without the extra pass over out1. */
+int lgu_offsets_finalize_masked(const void* o0, const void* o1, const float* probe, int T, float* out0, float* out1,
+                                void* scratch, int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps, void* stream) {
+  if (!probe || T < 2) return LGU_E_BADARG;
+  return offsets_finalize_impl(o0, o1, probe, T, out0, out1, scratch, E, C, H, W, Hl, Wl, is_half, eps, stream);
+}
+
+static int offsets_finalize_impl(const void* o0, const void* o1, const float* probe, int T, float* out0, float* out1, void* scratch,
+                                 int E, int C, int H, int W, int Hl, int Wl, int is_half, float eps, void* stream) {
   using namespace lgu;
   if (!o0 || !o1 || !out0 || !out1 || !scratch) return LGU_E_BADARG;
   if (E < 0 || C < 1 || H < 1 || W < 1 || Hl < 1 || Wl < 1) return LGU_E_BADARG;
@@ -284,6 +323,7 @@ int lgu_offsets_finalize(const void* o0, const void* o1, float* out0, float* out
   p.sy = (float)Hl / (float)H; p.sx = (float)Wl / (float)W;
   p.eps = eps;
   p.l1_f32 = is_half == 2;
+  p.probe = probe; p.T = T;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 g1(OF_CHUNKS, E), g2((H * W + OF_TP - 1) / OF_TP, E);
   if (is_half) {

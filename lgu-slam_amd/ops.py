@@ -691,12 +691,14 @@ def offset_conv_frames(frames, ii, jj, packed, frames_lo=None):
     return out
 
 
-def offsets_finalize(o0, o1_lowres, eps=1e-5, autocast=None):
+def offsets_finalize(o0, o1_lowres, eps=1e-5, autocast=None, probe=None):
     """Post-processing of the two offset convolutions' outputs (reference corr.py:117-135 / :217-235) in one pass:
     per-sample standardisation, 4*tanh, the level-1 residual mix, nearest upsampling of the pooled-resolution head and
     the transposition to the samplers' channel-last fp32 layout.  o0 (E,C,H,W), o1_lowres (E,C,Hl,Wl), both fp32 or
     both half.  Half inputs: every step rounded to half like torch's half kernels; with autocast (default: whether
     autocast is enabled now) level 1 is evaluated in fp32, because autocast promotes the nearest upsampling to fp32.
+    probe (optional, (E,T,H,W) or (E,1,T,H,W) fp32, T >= 2 samples per pixel): off1 additionally scaled by the uncertainty
+    mask sigmoid(var(probe)) of AltCorrBlock.corr_fn (corr.py:203-207) — what probe_mask_scale_ would do in a second pass.
     Returns (off0, off1), each (E,H,W,C) fp32."""
     if autocast is None:
         autocast = torch.is_autocast_enabled()
@@ -715,9 +717,18 @@ def offsets_finalize(o0, o1_lowres, eps=1e-5, autocast=None):
         return out0, out1
     lib = _lib.load()
     scratch = torch.empty(int(lib.lgu_offsets_finalize_scratch_bytes(E)), dtype=torch.uint8, device=o0.device)
+    mode = (2 if autocast else 1) if o0.dtype == torch.float16 else 0
     with torch.cuda.device(o0.device):
-        rc = lib.lgu_offsets_finalize(_ptr(o0), _ptr(o1_lowres), _ptr(out0), _ptr(out1), _ptr(scratch), E, C, H, W, Hl, Wl,
-                                      (2 if autocast else 1) if o0.dtype == torch.float16 else 0, float(eps), _stream(o0))
+        if probe is not None:
+            _check(probe, "probe")
+            T = probe.numel() // max(E * H * W, 1)
+            if probe.numel() != E * T * H * W or T < 2:
+                raise RuntimeError("offsets_finalize: probe must hold T >= 2 samples per pixel")
+            rc = lib.lgu_offsets_finalize_masked(_ptr(o0), _ptr(o1_lowres), _ptr(probe), T, _ptr(out0), _ptr(out1), _ptr(scratch), E, C,
+                                                 H, W, Hl, Wl, mode, float(eps), _stream(o0))
+        else:
+            rc = lib.lgu_offsets_finalize(_ptr(o0), _ptr(o1_lowres), _ptr(out0), _ptr(out1), _ptr(scratch), E, C, H, W, Hl, Wl,
+                                          mode, float(eps), _stream(o0))
     _lib.check(rc, "offsets_finalize")
     return out0, out1
 

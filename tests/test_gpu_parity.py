@@ -1749,3 +1749,18 @@ def test_altcorrblock_head_cache_on_and_off(lgu, monkeypatch):
         for x, y in zip(oa, ob):
             assert float((x - y).abs().max()) <= 2e-5
         assert float((ca - cb).abs().mean()) <= 1e-4
+
+
+def test_offsets_finalize_with_the_probe_mask_folded_in(lgu):
+    """ops.offsets_finalize(probe=...) (lgu_offsets_finalize_masked): level 1 leaves the post-processing already scaled by
+    the uncertainty mask — BIT FOR BIT what offsets_finalize followed by the in-place probe_mask_scale_ leaves (level 0
+    untouched), also on a pixel count that is not a multiple of the 32-pixel tile."""
+    torch.manual_seed(21)
+    for E, C, H, W in ((3, 98, 12, 20), (2, 98, 7, 9)):
+        o0 = torch.randn(E, C, H, W, device="cuda")
+        o1 = torch.randn(E, C, (H + 1) // 2, (W + 1) // 2, device="cuda")
+        probe = torch.randn(E, 1, 9, H, W, device="cuda")
+        a0, a1 = lgu.ops.offsets_finalize(o0, o1)
+        lgu.ops.probe_mask_scale_(probe, a1)
+        b0, b1 = lgu.ops.offsets_finalize(o0, o1, probe=probe)
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
