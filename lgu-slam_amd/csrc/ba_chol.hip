@@ -77,30 +77,39 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
     D[i][j] = v;
   }
   __syncthreads();
-  // (A one-barrier form — every thread keeps its entries and a running copy of their columns' pivots in registers — was
-  // built and measured: 36 against 29 us per launch; up to four root-and-divide sequences per thread on the critical path.)
-  for (int j = 0; j < w; j++) {
-    // every thread of column j takes the root of the pivot itself (no barrier between the pivot and the scaling)
-    if (t >= j && t < w) {
-      double d = D[j][j];
-      const bool bad = !(d > 0.0) || !(d < 1e300);
-      if (bad) d = 1.0;  // not positive definite: finish on a harmless pivot, x = 0 at the end
+  // The 32 x 32 block is factorised by ONE WAVE in registers: lane i holds row i, a pivot column reaches the other lanes
+  // through v_readlane (its entries are wave-uniform scalars there), no barrier and no LDS round trip inside the 32
+  // pivots.  (The barrier-paced forms — two barriers per pivot, or one with running pivots in registers — cost 26 / 33 us
+  // per block, whatever the number of rows behind it: 38 blocks of a 200-keyframe system.)
+  if (t < kWave) {
+    const int i = t & (CH_NB - 1);  // lanes 32..63 mirror lanes 0..31 and store nothing
+    double x[CH_NB];
+#pragma unroll
+    for (int k = 0; k < CH_NB; k++) x[k] = D[i][k];
+    auto bcast = [](double v, int lane) {
+      const long long bits = __builtin_bit_cast(long long, v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)bits, lane);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), lane);
+      return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
+    };
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) {
+      double d = bcast(x[j], j);  // pivot (wave-uniform)
+      if (!(d > 0.0) || !(d < 1e300)) { bad = true; d = 1.0; }  // not positive definite: finish on a harmless pivot, x = 0 at the end
       d = sqrt(d);
-      if (t == j) {
-        if (bad) *flag = 1;
-        dsq[j] = d;
-      } else {
-        D[t][j] /= d;
-      }
+      x[j] = i == j ? d : x[j] / d;  // column j: L_ij for i > j (rows above the diagonal carry don't-care values)
+#pragma unroll
+      for (int k = j + 1; k < CH_NB; k++) x[k] = __builtin_fma(-x[j], bcast(x[j], k), x[k]);  // a_ik -= L_ij L_kj
     }
-    __syncthreads();
-    if (t == 0) D[j][j] = dsq[j];
-    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_T) {
-      const int i = idx / CH_NB, k = idx - i * CH_NB;
-      if (k > j && i >= k && i < w) D[i][k] -= D[i][j] * D[k][j];
+    if (bad && t == 0) *flag = 1;
+    if (t < CH_NB) {
+#pragma unroll
+      for (int k = 0; k < CH_NB; k++)
+        if (k <= i) D[i][k] = x[k];
     }
-    __syncthreads();
   }
+  __syncthreads();
   // The factor of the block goes to a staging area, not into A: other workgroups of this launch may still be reading the
   // block.  The update launch that follows copies it in.
   if (blockIdx.x == 0)
