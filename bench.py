@@ -339,8 +339,13 @@ def lowmem_roofline(S, dev_ms):
     kern_s = dev_ms * 1e-3
     achieved = flop_unit * S["units"] / kern_s / 1e12
     hbm_unit = (1 + 1.328) * S["C"] * 2 + 784 + 784 + 8  # half maps: fmap1 + fmap2 pyramid, out, offsets of 2 levels, coords
+    traffic, tsrc = None, None
+    tfile = os.path.join(ROOT, "profiles", "traffic_r02_lowmem.json")
+    if os.path.exists(tfile) and S["B"] == 16:   # PMC passes of this same command (tools/gpu_lowmem_run.sh)
+        traffic, tsrc = json.load(open(tfile))["hbm_bytes_per_launch"], "profiles/traffic_r02_lowmem.json"
     return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-            "traffic": None, "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": tsrc,
+            "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
             "device_ms_per_step": dev_ms,
             "hbm_compulsory_bytes_per_unit": hbm_unit, "hbm_compulsory_GBps": hbm_unit * S["units"] / kern_s / 1e9,
             "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "

@@ -114,6 +114,25 @@ for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_call
                  ("pmc_lowmem.txt", "%s_pmc_lowmem_kernels.txt"), ("ba_kernel_stats.csv", "%s_ba_kernel_stats.csv")):
     if os.path.exists(os.path.join(G, src)) and os.path.getsize(os.path.join(G, src)) > 0:
         shutil.copy(os.path.join(G, src), os.path.join(P, dst % tag))
+# HBM traffic of the cooperative low-memory kernel per launch, from the PMC passes of tools/gpu_lowmem_run.sh
+pl = os.path.join(G, "pmc_lowmem.txt")
+if os.path.exists(pl):
+    vals = {}
+    for line in open(pl):
+        if line.startswith("== one-wave"):
+            break
+        f = line.split()
+        if "lowmem_coop_kernel" in line and ("FETCH_SIZE" in f or "WRITE_SIZE" in f):
+            vals["FETCH_SIZE" if "FETCH_SIZE" in f else "WRITE_SIZE"] = float(f[-1])
+    if len(vals) == 2:
+        json.dump({"kernel": "lgu::lowmem_coop_kernel<3, 4>", "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py "
+                   "--workload lowmem --edges 16 --no-cpu --steps 10 --warmup 2 --blocks 1 (separate runs; tools/run_pmc_coop.sh)",
+                   "fetch_size_KiB_raw": vals["FETCH_SIZE"], "write_size_KiB": vals["WRITE_SIZE"],
+                   "fetch_correction": "x2 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes; MI355X_MICROARCH.md, HBM)",
+                   "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+                   "units_per_launch": 16 * 60 * 80},
+                  open(os.path.join(P, "traffic_%s_lowmem.json" % tag), "w"), indent=1)
+
 json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py line (cold-cache headline + extra: probe on, row-major "
                    "operator path, warm cache, config 3, config 4), bench.py --workload lowmem / backend, rocprofv3 kernel-trace stats "
                    "and PMC traffic of the metric kernel in cold mode for both pyramid layouts, low-memory kernel trace, comparison "
