@@ -41,6 +41,12 @@ constexpr int CO_PP = 16 * CO_BOXP + 2;        // floats per patch (+2: consecut
 constexpr int CO_GUARD = 20;                   // floats in front of the patches (>= CO_BOXP + 1): see the sampling phase
 constexpr int CO_OUTP = 4 * CO_QP + 4;          // output transpose pitch
 constexpr int CO_MAXL = 4;
+// Alignment mask of the tile window's first column.  1: pairs of positions start at even columns (needed).  7 (build-time
+// A/B only): fragment loads start on 128-byte lines in the chunk-planar form — L2 read requests 4.22 -> 3.74 KB per
+// pixel-level, but the wider windows cost 2.5 % of time (112.3 against 109.6 us for config 4): not the default.
+#ifndef CO_XALIGN
+#define CO_XALIGN 1
+#endif
 constexpr int CO_LDS_FLOATS = CO_GUARD + CO_NPX * CO_PP + CO_NPX * 4 + 2 * CO_NW + 8;
 
 struct CoParams {
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       int TX0 = pk_lo(tlo);
       const int TY0 = pk_hi(tlo), TX1 = pk_lo(thi), TY1 = pk_hi(thi);
       if (TX1 >= TX0 && TY1 >= TY0) {
-        TX0 &= ~1;  // pairs of positions start at even columns
+        TX0 &= ~CO_XALIGN;  // pairs of positions start at even columns (CO_XALIGN = 1); 7: a fragment load (256 contiguous bytes per chunk in the chunk-planar form) then covers two 128-byte lines instead of three
         // per sub-block m, this lane's pixel (m, lx): byte address in LDS of the patch entry of (row 0 of the map, column
         // 4 lg of group 0), and the row / column ranges a store must fall in
         float* sbp[CO_SB];
