@@ -429,7 +429,9 @@ class AltCorrBlock:
             self._res_packed = ops.pack_offset_conv(res.weight, res.bias) if res_fast else None
             self._ofs_key = key
         frames0 = self.pyramid[0][0]
-        if getattr(self, "_pooled", None) is None:
+        pkey = (frames0.data_ptr(), frames0._version, res_fast)
+        if getattr(self, "_pooled", None) is None or getattr(self, "_pooled_key", None) != pkey:
+            self._pooled_key = pkey
             # 2 x 2 averages of the frames in fp32, as avg_pool2d of the reference's fp32 input gives them (x 4 is a power
             # of two and moves to the weights exactly), channel-last, split into two half parts: hi + lo == the average
             # to 2^-22.  The general path keeps the fp32 averages (x 4) in NCHW.
@@ -446,11 +448,12 @@ class AltCorrBlock:
                 # per-frame partial convolutions, kept for the life of this block (ops.OffsetHeadCache): the heads are
                 # linear in cat(frame ii, frame jj), a frame is source / target of ~10 edges each and the block serves
                 # every chunk of an update_lowmem pass, so each frame is convolved once and an edge costs a sum
-                if getattr(self, "_head_key", None) != key:
+                hkey = (key, frames0.data_ptr(), frames0._version)   # new weights or a rewritten pyramid: the partials are stale
+                if getattr(self, "_head_key", None) != hkey:
                     self._head0 = ops.OffsetHeadCache(frames0, ops.pack_offset_conv_parts(conv.weight, conv.bias))
                     self._head1 = ops.OffsetHeadCache(self._pooled[0], ops.pack_offset_conv_parts(res.weight, res.bias),
                                                       frames_lo=self._pooled[1])
-                    self._head_key = key
+                    self._head_key = hkey
                 E = iic.shape[0]
                 work = self._head0.mark(iic, jjc)   # one claim pass for both heads: they need the same frames
                 self._head0.convolve(work, E)
