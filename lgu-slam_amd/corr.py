@@ -383,7 +383,27 @@ class CorrBlock:
 
 
 class AltCorrBlock:
-    """Low-memory lookup: correlations recomputed from feature maps (reference corr.py:155-249)."""
+    """Low-memory lookup: correlations recomputed from feature maps (reference corr.py:155-249).
+
+    `offset` (the per-level learned offsets of the last call, reference attribute) is materialised on access: with one
+    sample per pixel the reference's sampler reads `offset[b * n]` with n = 0 for every edge b (lowMem_defSample.cu:80-83
+    — all edges of a call sample with the FIRST edge's offsets), so the fast path computes the offset heads, their
+    post-processing and the level-1 probe's mask for that edge only (LAZY_OFFSETS) and forms the other edges' rows — which
+    nothing on the path reads — only if somebody asks for the attribute."""
+
+    LAZY_OFFSETS = True
+
+    @property
+    def offset(self):
+        if getattr(self, "_lazy", None) is not None:
+            self._offset = self._materialise_offsets()
+            self._lazy = None
+        return self._offset
+
+    @offset.setter
+    def offset(self, value):
+        self._offset = value
+        self._lazy = None
 
     def __init__(self, ofsMap, ofs_residual, GA, fmaps, num_levels=4, radius=3):
         self.num_levels = num_levels
@@ -400,7 +420,7 @@ class AltCorrBlock:
             self.pyramid.append(lvl.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
             lvl = F.avg_pool2d(lvl, 2, stride=2)
 
-    def _offsets_from_frames(self, B, ii, jj, probe=None):
+    def _offsets_from_frames(self, B, ii, jj, probe=None, store=True):
         """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
         run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
         (E,256,H,W) tensor, fp32-accurate split-half weights).  The residual head's input, the 2 x 2 average of the
@@ -468,8 +488,27 @@ class AltCorrBlock:
                     o1_low = res(torch.cat((self._pooled[0][ii], self._pooled[0][jj]), dim=1))
         except _lib.UnsupportedShape:
             return False
-        self.offset, self._zero_level = finish_offsets(o0, o1_low, self.num_levels, probe=probe)   # probe: level 1 comes back masked
+        res_ = finish_offsets(o0, o1_low, self.num_levels, probe=probe)   # probe: level 1 comes back masked
+        if not store:
+            return res_
+        self.offset, self._zero_level = res_
         return True
+
+    def _materialise_offsets(self):
+        """Every edge's offsets of the last (lazy) call, as the reference's attribute holds them: the full heads and
+        post-processing (same kernels per sample), with the first edge's rows taken from the tensors the lookup actually
+        used (their centre taps zeroed by the sampler, lowMem_defSample.cu:80-81)."""
+        iic, jjc, run_probe, E, offs = self._lazy
+        full = self._offsets_from_frames(1, iic, jjc, probe=run_probe(E), store=False)
+        if full is False:   # cannot happen: the same path just served the first edge
+            raise RuntimeError("AltCorrBlock: offsets of the last call are no longer available")
+        rows, _ = full
+        rows = list(rows)
+        for i, o in enumerate(offs):
+            if o is not None:
+                rows[i] = rows[i].contiguous()
+                rows[i][:1] = o.view(rows[i][:1].shape)
+        return rows
 
     def corr_fn(self, coords, ii, jj):
         B, N, H, W, S, _ = coords.shape
@@ -512,8 +551,31 @@ class AltCorrBlock:
                     self._chunked = [ops.lowmem_chunked(f) for f in frames]
                 iic, jjc = ii.contiguous(), jj.contiguous()
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
-                probe = ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], c0, [None], 1, ii=iic, jj=jjc, lbase=1,
-                                                         chunked=True)
+            except _lib.UnsupportedShape:
+                fused_ok = False
+
+        def run_probe(n_edges):   # the plain r = 1 samples of level 1 (corr.py:201-202) for the first n_edges edges
+            return ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], c0[:n_edges], [None], 1, ii=iic[:n_edges],
+                                                    jj=jjc[:n_edges], lbase=1, chunked=True)
+
+        if fused_ok and self.LAZY_OFFSETS and not torch.is_grad_enabled():
+            # Only the first edge's offsets are ever read (class docstring): probe, heads, post-processing for that edge.
+            try:
+                i0, j0 = iic[:1], jjc[:1]
+                first = self._offsets_from_frames(B, i0, j0, probe=run_probe(1), store=False)
+                if first is not False:
+                    rows, zero_level = first
+                    offs = [None if zero_level[i] else rows[i].contiguous().view(1, H, W, rd, rd, 2).float()
+                            for i in range(self.num_levels)]
+                    fused = ops.lowmem_pyramid_forward_mixed(frames[0], self._chunked, c0, offs, self.radius, ii=iic, jj=jjc, chunked=True)
+                    self._offset, self._zero_level = None, zero_level
+                    self._lazy = (iic, jjc, run_probe, B * N, offs)   # what `offset` needs to form every edge's rows on demand
+                    return fused.view(B, N, -1, H, W).unsqueeze(-1)   # (1,E,L*rd*rd,H,W,S=1)
+            except _lib.UnsupportedShape:
+                pass
+        if fused_ok:
+            try:
+                probe = run_probe(B * N)
             except _lib.UnsupportedShape:
                 fused_ok, probe = False, None
 
