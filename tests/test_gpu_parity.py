@@ -1764,3 +1764,36 @@ def test_offsets_finalize_with_the_probe_mask_folded_in(lgu):
         lgu.ops.probe_mask_scale_(probe, a1)
         b0, b1 = lgu.ops.offsets_finalize(o0, o1, probe=probe)
         assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_altcorrblock_lazy_first_edge_offsets(lgu, monkeypatch):
+    """AltCorrBlock.LAZY_OFFSETS: with one sample per pixel the reference's sampler reads offset[b * n] with n = 0
+    (lowMem_defSample.cu:80-83) — every edge of a call samples with the FIRST edge's offsets — so the fast path computes
+    probe, heads and post-processing for that edge only.  The lookup is BIT-IDENTICAL to the block that computes every
+    edge's offsets, and the `offset` attribute, materialised on access, holds the same tensors bit for bit (the first
+    edge's centre taps zeroed by the sampler in both)."""
+    torch.manual_seed(17)
+    N, C, H, W = 7, 128, 20, 28
+    fmaps = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    ii = torch.tensor([2, 2, 3, 4, 4, 5], device="cuda")
+    jj = torch.tensor([3, 4, 2, 5, 6, 4], device="cuda")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, ii.numel(), H, W, 2, device="cuda")).contiguous()
+    res = {}
+    with torch.no_grad():
+        for lazy in (True, False):
+            monkeypatch.setattr(lgu.AltCorrBlock, "LAZY_OFFSETS", lazy)
+            blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+            out = blk(coords, ii, jj)
+            assert (getattr(blk, "_lazy", None) is not None) == lazy
+            offs = [o.clone() for o in blk.offset]       # materialises in lazy mode
+            assert getattr(blk, "_lazy", None) is None
+            res[lazy] = (out.clone(), offs)
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    cen = 3 * 7 + 3
+    assert not res[True][1][0][0].view(H, W, 49, 2)[:, :, cen].any()          # edge 0: centre taps zeroed by the sampler
+    assert res[True][1][0][1].view(H, W, 49, 2)[:, :, cen].any()              # other edges: never touched
