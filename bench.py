@@ -475,14 +475,22 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
     sens = torch.zeros_like(disps0)
     poses, disps = poses0.clone(), disps0.clone()
 
-    def chunk_fn(idx, iis):
+    # per chunk: its edges' positions among its source frames and the frames' edge counts (graph bookkeeping, once)
+    chunk_tab = {}
+    for idx in edges.my_chunks:
+        fr, inv = torch.unique(ii[idx], return_inverse=True)
+        chunk_tab[id(idx)] = (inv, fr.numel(), torch.bincount(inv, minlength=fr.numel()).view(-1, 1, 1).float())  # idx: the set's own tensor
+    one_launch = not args.chunk_loop
+
+    def chunk_fn(idx, iis, corr=None):
         with torch.no_grad():
-            corr = sac.block(coords1[:, idx], iis, jjs_of(idx))[0]            # (n,196,H,W)
+            if corr is None:   # the reference's loop: one corr_fn call per chunk (factor_graph.py:272-279)
+                corr = sac.block(coords1[:, idx], iis, jjs_of(idx))
+            corr = corr[0]                                                    # (n,196,H,W)
             t = coords1[0, idx] + 0.05 * corr[:, 0:2].permute(0, 2, 3, 1)
             w = torch.sigmoid(corr[:, 2:4].permute(0, 2, 3, 1))
-            fr, inv = torch.unique(iis, return_inverse=True)
-            d = torch.zeros(fr.numel(), H, W, device=dev).index_add_(0, inv, torch.sigmoid(corr[:, 4]))
-            d = d / torch.bincount(inv, minlength=fr.numel()).view(-1, 1, 1).float()
+            inv, nf, cnt = chunk_tab[id(idx)]
+            d = torch.zeros(nf, H, W, device=dev).index_add_(0, inv, torch.sigmoid(corr[:, 4])) / cnt
         return t, w, d
 
     def jjs_of(idx):
@@ -504,7 +512,12 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
             sac.block = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
         it_no[0] += 1
         ev[0].record()
-        local = sh.run_chunks(edges, ii, chunk_fn)
+        if one_launch:   # all of this rank's chunks in one lookup launch (ShardedAltCorr.lookup_all), then the update stand-in per chunk
+            with torch.no_grad():
+                _, corr_all, _ = sac.lookup_all(coords1)
+            local = sh.run_chunks(edges, ii, chunk_fn, corr_all=corr_all)
+        else:
+            local = sh.run_chunks(edges, ii, chunk_fn)
         ev[1].record()
         sh.exchange_step(edges, local, target, weight, damping)
         ev[2].record()
@@ -552,6 +565,8 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                                      "replicated dense BA (2 iterations)" % (E, N, world),
                          "edges_total": E, "edges_this_rank": int(edges.counts[rank]), "chunks_this_rank": len(edges.my_chunks),
                          "units_per_step": units, "update_operator": "stand-in (out of scope)",
+                         "lookups": "one launch for all of the rank's chunks (AltCorrBlock.call_many: every chunk's results bit-identical "
+                                    "to its own call)" if one_launch else "one call per chunk (--chunk-loop: the reference's loop)",
                          "ba": "lgu_slam_amd.ba (experimental: parity unpinned)"},
               "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2],
                                            "corr_block_per_step": ph[3]},
@@ -625,6 +640,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the 'extra' figures (probe on, row-major operator path, "
                     "config 3, config 4, warm cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--chunk-loop", action="store_true", help="backend workload: one lookup call per source-frame chunk, as the "
+                    "reference's update_lowmem issues them, instead of ONE launch for all of the rank's chunks (the default; same results)")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed steps one by one from Python instead of replaying "
                                                              "them from one HIP graph")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")

@@ -332,6 +332,21 @@ int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* f
                                        int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
                                        int radius, const long long* ii, const long long* jj, void* stream);
 
+/* SEVERAL calls of AltCorrBlock.corr_fn in ONE launch (the chunk loop of update_lowmem, reference
+ * droid_slam/factor_graph.py:272-279, runs one corr_fn call per chunk of source frames only to bound memory).  The B
+ * edges are the calls' edges back to back, one sample per pixel (S = 1); `offsets[l]` holds NO rows (NO = number of
+ * calls), row k = the offsets of call k's FIRST edge — the only row the reference's sampler reads in a call:
+ * offset[b*n] with n = 0 (offersample_LGS/lowMem_defSample.cu:80-83) — and off_row (device, B ints, values in [0, NO))
+ * names each edge's call.  Edge b's results are, bit for bit, those of lgu_lowmem_pyramid_(chunked_)fwd_h16 over its
+ * call alone.  coords (B,1,H1,W1,2), out (B,1,L*rd*rd,H1,W1).  chunked != 0: fmap2 levels in the chunk-planar form.
+ * Half maps with C in {32,64,128}, radius 1..3 (the cooperative kernel); LGU_E_UNSUPPORTED otherwise — the caller
+ * then issues the calls one by one.  Out-of-range off_row values are clamped to [0, NO) on the device. */
+int lgu_lowmem_pyramid_calls_fwd_h16(const void* fmap1_half, const void* const* fmap2_half, const float* coords,
+                                     float* const* offsets, float* out,
+                                     int L, int lbase, int B, int H1, int W1, const int* H2, const int* W2, int C, int NO,
+                                     const int* off_row, int radius, const long long* ii, const long long* jj, int chunked,
+                                     void* stream);
+
 /* ---- dense bundle adjustment: device kernels (first version) ---------------------------
  * The data-parallel kernels of droid_backends.ba (reference src/droid.cpp:88-107 -> src/droid_kernels.cu:1314-1434).
  * The reference's host driver copies every block to the CPU and solves with Eigen; here lgu-slam_amd/ba.py assembles

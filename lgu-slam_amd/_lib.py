@@ -48,6 +48,9 @@ SIGNATURES = {
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
     "lgu_lowmem_pyramid_chunked_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
+    # fmap1, fmap2[], coords, offsets[], out, L, lbase, B, H1, W1, H2[], W2[], C, NO, off_row, radius, ii, jj, chunked, stream
+    "lgu_lowmem_pyramid_calls_fwd_h16": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int,
+                                         ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _vp, _int, _vp, _vp, _int, _vp],
     "lgu_lowmem_pyramid_fwd_f32": [_vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), _vp, _int, _int, _int, _int, _int, _int,
                                    ctypes.POINTER(_int), ctypes.POINTER(_int), _int, _int, _int, _vp, _vp, _vp],
     "lgu_ba_build_f32": [_vp] * 14 + [_int] * 3 + [_vp],

@@ -420,6 +420,80 @@ class AltCorrBlock:
             self.pyramid.append(lvl.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
             lvl = F.avg_pool2d(lvl, 2, stride=2)
 
+    def _frame_operands(self):
+        """The stored pyramid as the fused launches read it: per level (N,Hl,Wl,C) views (float copies of a float
+        pyramid's levels) and, in self._chunked, the chunk-planar form the matrix-core sweep reads the target maps in
+        (ops.lowmem_chunked: 16 x-adjacent positions of a 16-byte channel chunk are contiguous) — made once per block, like
+        the pyramid itself."""
+        frames = [p_[0].contiguous() for p_ in self.pyramid]
+        if self.pyramid[0].dtype != torch.float16:
+            frames = [f.float() for f in frames]
+        if getattr(self, "_chunked", None) is None or self._chunked[0].dtype != frames[0].dtype:
+            self._chunked = [ops.lowmem_chunked(f) for f in frames]
+        return frames
+
+    def call_many(self, coords, ii, jj, counts):
+        """`torch.cat([self(coords[:, s:e], ii[s:e], jj[s:e]) for the consecutive edge ranges of lengths counts], dim=1)`
+        — the chunk loop of update_lowmem (reference factor_graph.py:272-279), which issues one corr_fn call per chunk of
+        source frames only to bound memory — in ONE lookup launch (ops.LowmemPyramidPlan(off_row=...)) behind ONE batched
+        pass of the probe, the offset heads and their post-processing over the calls' first edges: a call's edges all
+        sample with its first edge's offsets (class docstring), so each call contributes one offset row.  Every edge's
+        result is bit for bit that of its own call.  `offset` afterwards is the LAST call's, as after the loop.  Inputs the
+        fused launch does not serve (gradients, S > 1, float maps, ...) are issued call by call."""
+        counts = [int(c) for c in counts]
+        E = ii.shape[0]
+        if sum(counts) != E or coords.shape[1] != E or any(c <= 0 for c in counts):
+            raise RuntimeError("call_many: counts must be positive and add up to the number of edges")
+        squeeze = coords.dim() == 5
+        starts = [0]
+        for c in counts[:-1]:
+            starts.append(starts[-1] + c)
+
+        def one_by_one():
+            return torch.cat([self(coords[:, s:s + c], ii[s:s + c], jj[s:s + c]) for s, c in zip(starts, counts)], dim=1)
+
+        B, H, W = coords.shape[0], coords.shape[2], coords.shape[3]
+        S = 1 if squeeze else coords.shape[4]
+        rd = 2 * self.radius + 1
+        if not (len(counts) > 1 and self.LAZY_OFFSETS and not torch.is_grad_enabled() and S == 1 and B == 1
+                and self.num_levels >= 2 and self.pyramid[0].dtype == torch.float16 and ii.dtype == torch.int64
+                and jj.dtype == torch.int64):
+            return one_by_one()
+        try:
+            frames = self._frame_operands()
+            K = len(counts)
+            ckey = (tuple(counts), ii.device)
+            if getattr(self, "_calls_key", None) != ckey:   # edge -> call tables, uploaded once per partition
+                self._calls_first = torch.tensor(starts, device=ii.device)
+                self._calls_row = torch.repeat_interleave(torch.arange(K, dtype=torch.int32, device=ii.device),
+                                                          torch.tensor(counts, device=ii.device)).contiguous()
+                self._calls_key = ckey
+            first, off_row = self._calls_first, self._calls_row
+            iic, jjc = ii.contiguous(), jj.contiguous()
+            c0 = coords.reshape(E, 1, H, W, 2).contiguous()
+            i0, j0 = iic[first], jjc[first]
+
+            def probe_of(cs, i_, j_):   # the plain r = 1 samples of level 1 (corr.py:201-202)
+                return ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], cs, [None], 1, ii=i_, jj=j_, lbase=1,
+                                                        chunked=True)
+
+            firsts = self._offsets_from_frames(1, i0, j0, probe=probe_of(c0[first], i0, j0), store=False)
+            if firsts is False:
+                return one_by_one()
+            rows, zero_level = firsts
+            offs = [None if zero_level[i] else rows[i].contiguous().view(K, H, W, rd, rd, 2).float()
+                    for i in range(self.num_levels)]
+            fused = ops.lowmem_pyramid_forward_mixed(frames[0], self._chunked, c0, offs, self.radius, ii=iic, jj=jjc,
+                                                     chunked=True, off_row=off_row)
+        except _lib.UnsupportedShape:
+            return one_by_one()
+        sl, nl = starts[-1], counts[-1]
+        il, jl, cl = iic[sl:], jjc[sl:], c0[sl:]
+        self._offset, self._zero_level = None, zero_level
+        self._lazy = (il, jl, lambda n: probe_of(cl[:n], il[:n], jl[:n]), nl, [None if o is None else o[K - 1:] for o in offs])
+        out = fused.view(1, E, -1, H, W)
+        return out if squeeze else out.unsqueeze(-1)
+
     def _offsets_from_frames(self, B, ii, jj, probe=None, store=True):
         """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
         run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
@@ -542,13 +616,7 @@ class AltCorrBlock:
         probe = frames = iic = jjc = c0 = None
         if fused_ok:
             try:
-                frames = [p_[0].contiguous() for p_ in self.pyramid]            # (N,Hl,Wl,C): views of the stored pyramid
-                if not mixed:
-                    frames = [f.float() for f in frames]
-                # the matrix-core sweep reads the target maps in the chunk-planar form (ops.lowmem_chunked: 16 x-adjacent
-                # positions of a 16-byte channel chunk are contiguous): made once per block, like the pyramid itself
-                if getattr(self, "_chunked", None) is None or self._chunked[0].dtype != frames[0].dtype:
-                    self._chunked = [ops.lowmem_chunked(f) for f in frames]
+                frames = self._frame_operands()
                 iic, jjc = ii.contiguous(), jj.contiguous()
                 c0 = coords.reshape(B * N, S, H, W, 2).contiguous()
             except _lib.UnsupportedShape:

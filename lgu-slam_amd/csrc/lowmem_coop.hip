@@ -66,6 +66,10 @@ struct CoParams {
   int n_fused, n_split, ngroups, gl0[CO_MAXL + 1];
   const long long* ii;
   const long long* jj;
+  // Several reference calls in one launch (lgu_lowmem_pyramid_calls_fwd_h16): edge b samples with offset row orow[b] — the
+  // first edge of ITS call — instead of row b*n.  Null = one call.  Values are clamped to n_orow - 1 (no wild reads).
+  const int* orow;
+  int n_orow;
 };
 
 // the four corner dots of one tap straight from memory (boxes larger than the patch)
@@ -179,9 +183,10 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
   // Levels are served coarse to fine.  A level's offsets (16 registers) are requested one step ahead of their use: right
   // after the sampling of the level before it, so they travel during that level's write-out and the barrier (held across
   // a whole zero-offset level they cost 16 registers where the kernel has none to spare).
+  const int orow_b = p.orow ? min(max(p.orow[b], 0), p.n_orow - 1) : b * n;
   auto level_offsets = [&](int l) -> float* {  // workgroup-uniform; reference indexing kept: offset[b*n] (lowMem_defSample.cu:80-83)
     float* o = p.offset[l];
-    return o ? o + (size_t)(b * n) * HW1 * NT * 2 : nullptr;
+    return o ? o + (size_t)orow_b * HW1 * NT * 2 : nullptr;
   };
   float2 o0[CO_QP][TI];
   auto request_offsets = [&](int l) __attribute__((always_inline)) {  // offsets of level l, if it is served here and has any
@@ -607,8 +612,10 @@ static int launch_coop(CoParams p, hipStream_t st) {
 // one-wave-per-block kernel of lowmem_mfma.hip).  LGU_LOWMEM_COOP=0 (debug / A-B only) disables it.
 int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
                          const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int lbase,
-                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, hipStream_t st) {
+                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, const int* orow, int n_orow,
+                         hipStream_t st) {
   if (env_int("LGU_LOWMEM_COOP", 1) == 0) return -1;
+  if (orow && (S != 1 || n_orow < 1)) return -1;
   if (L < 1 || L > CO_MAXL || radius < 1 || radius > 3 || S > 65535) return -1;
   // a single zero-offset level (altcorr_forward; the r = 1 probe of AltCorrBlock) has little window to share and no
   // offsets to wait for: the independent waves of the one-wave kernel serve it faster (probe: 18 against 25 us)
@@ -628,6 +635,7 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   p.coords = coords; p.corr = corr;
   p.L = L; p.B = B; p.S = S; p.H1 = H1; p.W1 = W1;
   p.lbase = lbase; p.lvl0 = lvl0; p.Ltot = Ltot; p.f2_chunked = f2_chunked; p.ii = ii; p.jj = jj;
+  p.orow = orow; p.n_orow = n_orow;
 #define LGU_CO_CASE(RV, KSV) \
   if (radius == RV && C == 32 * KSV) return launch_coop<RV, KSV>(p, st);
   LGU_CO_CASE(3, 4) LGU_CO_CASE(1, 4) LGU_CO_CASE(2, 4)
@@ -646,7 +654,7 @@ int lgu_co_diag_set_stamps(void* q) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(l
 int lgu_co_diag_pyramid(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
                         const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int chunked) {
   return lgu::lowmem_coop_dispatch(fmap1, fmap2, offset, coords, corr, H2, W2, L, B, S, H1, W1, C, radius, 0, 0, L, chunked,
-                                   nullptr, nullptr, nullptr);
+                                   nullptr, nullptr, nullptr, 0, nullptr);
 }
 }
 #endif

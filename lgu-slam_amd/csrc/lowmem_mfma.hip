@@ -151,6 +151,8 @@ struct MmParams {
   int f2_chunked;
   const long long* ii;   // optional frame indices (device, int64): edge b reads fmap1[ii[b]] and fmap2[l][jj[b]]
   const long long* jj;   // straight from the frame buffers — no gathered per-edge copies; null = fmap*[b]
+  const int* orow;       // optional (device, B ints; cooperative kernel only): offset row of edge b, see lgu_lowmem_pyramid_calls_fwd_h16
+  int n_orow;
 };
 
 // One wave = one workgroup = a block of MT 4 x 4 pixel sub-blocks side by side (4 rows x 4 MT columns).  Every B
@@ -579,15 +581,17 @@ static int launch_mfma(const MmParams& p, hipStream_t st) {
 // lowmem_coop.hip: four waves share the swept windows, all levels in one wave life (half maps, C <= 128)
 int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* const* offset, const float* coords, float* corr,
                          const int* H2, const int* W2, int L, int B, int S, int H1, int W1, int C, int radius, int lbase,
-                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, hipStream_t st);
+                         int lvl0, int Ltot, int f2_chunked, const long long* ii, const long long* jj, const int* orow, int n_orow,
+                         hipStream_t st);
 
 template <typename T>
 static int mfma_dispatch(const MmParams& p, int C, int radius, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     const int rc = lowmem_coop_dispatch(p.fmap1, p.fmap2, p.offset, p.coords, p.corr, p.H2, p.W2, p.L, p.B, p.S, p.H1, p.W1, C,
-                                        radius, p.lbase, p.lvl0, p.Ltot, p.f2_chunked, p.ii, p.jj, st);
+                                        radius, p.lbase, p.lvl0, p.Ltot, p.f2_chunked, p.ii, p.jj, p.orow, p.n_orow, st);
     if (rc >= 0) return rc;
   }
+  if (p.orow) return -1;  // only the cooperative kernel knows offset rows per edge
   uintptr_t al = reinterpret_cast<uintptr_t>(p.fmap1);
   for (int l = 0; l < p.L; l++) al |= reinterpret_cast<uintptr_t>(p.fmap2[l]);
   if (radius < 1 || radius > 3 || (al & 15) != 0 || p.S > 65535) return -1;
@@ -630,13 +634,16 @@ extern "C" {
 
 static int pyramid_entry(bool half, const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
                          float* out, int L, int lbase, int B, int S, int H1, int W1, const int* H2, const int* W2, int C, int NO,
-                         int radius, const long long* ii, const long long* jj, void* stream, bool chunked = false) {
+                         int radius, const long long* ii, const long long* jj, void* stream, bool chunked = false,
+                         const int* orow = nullptr) {
   using namespace lgu;
+  if (orow && (S != 1 || NO < 1)) return LGU_E_BADARG;
   if (!fmap1 || !fmap2 || !coords || !offsets || !out || !H2 || !W2) return LGU_E_BADARG;
   if (L < 1 || L > MM_MAXL || lbase < 0 || lbase > 16 || B < 0 || S < 1 || H1 < 1 || W1 < 1 || C < 1 || radius < 0)
     return LGU_E_BADARG;
   if ((long long)(B - 1) * (S - 1) >= (long long)NO || (ii == nullptr) != (jj == nullptr)) return LGU_E_BADARG;
   MmParams p = {};
+  p.orow = orow; p.n_orow = NO;
   p.fmap1 = fmap1;
   for (int l = 0; l < L; l++) {
     if (!fmap2[l] || H2[l] < 1 || W2[l] < 1) return LGU_E_BADARG;
@@ -681,6 +688,15 @@ int lgu_lowmem_pyramid_chunked_fwd_f32(const float* fmap1, const float* const* f
                                        const long long* jj, void* stream) {
   return pyramid_entry(false, fmap1, reinterpret_cast<const void* const*>(fmap2), coords, offsets, out, L, lbase, B, S, H1, W1,
                        H2, W2, C, NO, radius, ii, jj, stream, true);
+}
+
+int lgu_lowmem_pyramid_calls_fwd_h16(const void* fmap1, const void* const* fmap2, const float* coords, float* const* offsets,
+                                     float* out, int L, int lbase, int B, int H1, int W1, const int* H2, const int* W2, int C,
+                                     int NO, const int* off_row, int radius, const long long* ii, const long long* jj,
+                                     int chunked, void* stream) {
+  if (!off_row) return LGU_E_BADARG;
+  return pyramid_entry(true, fmap1, fmap2, coords, offsets, out, L, lbase, B, 1, H1, W1, H2, W2, C, NO, radius, ii, jj, stream,
+                       chunked != 0, off_row);
 }
 
 }  // extern "C"

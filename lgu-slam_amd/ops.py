@@ -288,9 +288,12 @@ class LowmemPyramidPlan:
     The pointer tables are built once; a call costs one ctypes invocation.  Raises UnsupportedShape (at the first
     call) for channel counts / radii the matrix-core kernel does not serve."""
 
-    def __init__(self, fmap1, fmap2s, offsets, radius, ii=None, jj=None, lbase=0, chunked=False):
+    def __init__(self, fmap1, fmap2s, offsets, radius, ii=None, jj=None, lbase=0, chunked=False, off_row=None):
         """chunked=True: every fmap2s[l] is in the chunk-planar form of lowmem_chunked() — (F, C/k, H2l, W2l, k) — instead
-        of channel-last (F, H2l, W2l, C); same results bit for bit, the sweep's loads become line-friendly."""
+        of channel-last (F, H2l, W2l, C); same results bit for bit, the sweep's loads become line-friendly.
+        off_row (int32 device tensor of length B, values < rows of the offset tensors): SEVERAL reference calls in one
+        launch — edge b samples with offset row off_row[b], the first edge of its call (lgu_lowmem_pyramid_calls_fwd_h16:
+        half maps, one sample per pixel); every edge's result is that of its own call."""
         L = len(fmap2s)
         if len(offsets) != L or not 1 <= L <= 4:
             raise RuntimeError("LowmemPyramidPlan: need 1..4 levels and one offset entry (tensor or None) per level")
@@ -324,7 +327,20 @@ class LowmemPyramidPlan:
         self._ii = ii.data_ptr() if ii is not None and self.B else None
         self._jj = jj.data_ptr() if jj is not None and self.B else None
         lib = _lib.load()
-        if chunked:
+        self._rows = None
+        if off_row is not None:
+            _check_dtype(off_row, "off_row", torch.int32)
+            if dt != torch.float16 or off_row.dim() != 1 or off_row.shape[0] != self.B or not off_row.is_contiguous():
+                raise RuntimeError("LowmemPyramidPlan: off_row needs half feature maps and one int32 entry per edge")
+            rows = {o.shape[0] for o in offsets if o is not None}
+            if len(rows) > 1:
+                raise RuntimeError("LowmemPyramidPlan: with off_row every offset tensor holds one row per call")
+            self.NO = rows.pop() if rows else 1
+            self._keep = self._keep + (off_row,)
+            self._rows = off_row.data_ptr() if self.B else None
+            self._chunked = 1 if chunked else 0
+            self._fn = lib.lgu_lowmem_pyramid_calls_fwd_h16
+        elif chunked:
             self._fn = lib.lgu_lowmem_pyramid_chunked_fwd_h16 if dt == torch.float16 else lib.lgu_lowmem_pyramid_chunked_fwd_f32
         else:
             self._fn = lib.lgu_lowmem_pyramid_fwd_h16 if dt == torch.float16 else lib.lgu_lowmem_pyramid_fwd_f32
@@ -338,6 +354,14 @@ class LowmemPyramidPlan:
         if out is None:
             out = torch.empty((B, S, ch, H1, W1), dtype=torch.float32, device=self.device)
         if B == 0:
+            return out
+        if self._rows is not None:
+            if S != 1:
+                raise RuntimeError("LowmemPyramidPlan: off_row serves one sample per pixel")
+            rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B,
+                          H1, W1, self._h2, self._w2, self.C, self.NO, self._rows, self.radius, self._ii, self._jj,
+                          self._chunked, torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(rc, "lowmem_pyramid_forward (several calls)")
             return out
         rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B, S,
                       H1, W1, self._h2, self._w2, self.C, self.NO, self.radius, self._ii, self._jj,
@@ -356,10 +380,12 @@ def lowmem_chunked(fmap):
     return fmap.view(F, H, W, C // k, k).permute(0, 3, 1, 2, 4).contiguous()
 
 
-def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None, ii=None, jj=None, lbase=0, chunked=False):
+def lowmem_pyramid_forward_mixed(fmap1, fmap2s, coords, offsets, radius, out=None, ii=None, jj=None, lbase=0, chunked=False,
+                                 off_row=None):
     """One-shot form of LowmemPyramidPlan (half or float feature maps)."""
     with torch.cuda.device(fmap1.device):
-        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius, ii=ii, jj=jj, lbase=lbase, chunked=chunked)(coords, out=out)
+        return LowmemPyramidPlan(fmap1, fmap2s, offsets, radius, ii=ii, jj=jj, lbase=lbase, chunked=chunked,
+                                 off_row=off_row)(coords, out=out)
 
 
 PYR_PROBE, PYR_TILED, PYR_COORDS_LAST = 1, 2, 4  # flags of lgu_defcorr_pyramid_fwd_f32 (include/lgu_corr.h)

@@ -220,15 +220,34 @@ class ShardedAltCorr:
             iis, jjs = self.ii[idx], self.jj[idx]
             yield idx, self.block(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long())
 
+    def lookup_all(self, coords1):
+        """All of this rank's chunks in ONE lookup launch (AltCorrBlock.call_many): returns (edge_index_tensor =
+        edges.my_edges, corr (1,n,196,H,W), counts) with the chunks' edges back to back in chunk order; every chunk's
+        slice is bit for bit what `lookup` yields for it.  The reference's loop issues one call per chunk only to bound
+        memory (factor_graph.py:272-279); 250 edges of 60 x 80 lookups are 0.9 GB here."""
+        idx = self.edges.my_edges
+        counts = [int(c.numel()) for c in self.edges.my_chunks]
+        if not counts:
+            return idx, None, counts
+        iis, jjs = self.ii[idx], self.jj[idx]
+        return idx, self.block.call_many(coords1[:, idx], self.rig * iis, self.rig * jjs + (iis == jjs).long(), counts), counts
 
-def run_chunks(edges, ii, chunk_fn, with_upmask=False):
+
+def run_chunks(edges, ii, chunk_fn, with_upmask=False, corr_all=None):
     """This rank's part of the chunk loop of update_lowmem (reference factor_graph.py:272-292): chunk_fn(idx, iis) ->
     (target (n,ht,wd,2), weight (n,ht,wd,2), damping (f,ht,wd)[, upmask (f,...)]) for the edges `idx` of one chunk
     (iis = their source frames, f = torch.unique(iis).numel(), frames ascending) — the caller's correlation lookup +
-    update operator.  Returns the per-chunk results as lists (target, weight, damping, upmask) in chunk order."""
+    update operator.  Returns the per-chunk results as lists (target, weight, damping, upmask) in chunk order.
+    corr_all = the (1,n,C,H,W) result of ShardedAltCorr.lookup_all: the lookups were done in one launch and chunk_fn is
+    called as chunk_fn(idx, iis, corr) with its chunk's slice (a view)."""
     t_loc, w_loc, d_loc, u_loc = [], [], [], []
+    pos = 0
     for idx in edges.my_chunks:
-        r = chunk_fn(idx, ii[idx])
+        if corr_all is not None:
+            r = chunk_fn(idx, ii[idx], corr_all[:, pos:pos + idx.numel()])
+            pos += idx.numel()
+        else:
+            r = chunk_fn(idx, ii[idx])
         t_loc.append(r[0]); w_loc.append(r[1]); d_loc.append(r[2])
         if with_upmask:
             u_loc.append(r[3])

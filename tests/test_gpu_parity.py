@@ -1797,3 +1797,87 @@ def test_altcorrblock_lazy_first_edge_offsets(lgu, monkeypatch):
     cen = 3 * 7 + 3
     assert not res[True][1][0][0].view(H, W, 49, 2)[:, :, cen].any()          # edge 0: centre taps zeroed by the sampler
     assert res[True][1][0][1].view(H, W, 49, 2)[:, :, cen].any()              # other edges: never touched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(20, 28), (18, 28)])
+def test_altcorrblock_call_many_equals_the_calls_one_by_one(lgu, oracle, shape):
+    """AltCorrBlock.call_many / ShardedAltCorr.lookup_all: the chunk loop of update_lowmem (factor_graph.py:272-279, one
+    corr_fn call per chunk of source frames) in ONE lookup launch, every call contributing the offset row of its first edge
+    (lgu_lowmem_pyramid_calls_fwd_h16).  Bit-identical to the calls issued one by one — and the first call additionally
+    checked against the oracle's sampler over the first edge's offsets (1e-5) — and `offset` afterwards is the last
+    call's.  Chunks of uneven sizes including a single-edge one; odd level sizes (9 x 14, 4 x 7, 2 x 3).  (Shapes the
+    head cache does not serve run the torch composition call by call, whose convolutions are not bit-reproducible.)"""
+    torch.manual_seed(23)
+    H, W = shape
+    N, C = 9, 128
+    fmaps = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    ii = torch.tensor([0, 0, 1, 1, 1, 2, 3, 3, 4, 5, 5, 6, 7, 8, 8], device="cuda")
+    jj = torch.tensor([1, 2, 0, 2, 3, 3, 4, 2, 5, 4, 6, 7, 8, 7, 6], device="cuda")
+    counts = [5, 1, 3, 4, 2]
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, ii.numel(), H, W, 2, device="cuda")).contiguous()
+    with torch.no_grad():
+        blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        many = blk.call_many(coords, ii, jj, counts)
+        assert getattr(blk, "_calls_key", None) is not None        # the one-launch path ran, not the fallback loop
+        off_many = [o.clone() for o in blk.offset]
+        ref_blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        parts, s = [], 0
+        for c in counts:
+            parts.append(ref_blk(coords[:, s:s + c], ii[s:s + c], jj[s:s + c]))
+            s += c
+        off_loop = [o.clone() for o in ref_blk.offset]
+    assert many.shape == (1, ii.numel(), 4 * 49, H, W)
+    assert torch.equal(many, torch.cat(parts, dim=1))
+    for a, b in zip(off_many, off_loop):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # a second pass over the same partition reuses the tables and the head cache
+    with torch.no_grad():
+        assert torch.equal(blk.call_many(coords, ii, jj, counts), many)
+        # six-dimensional coords (explicit sample axis) and the fallback loop (counts of one call)
+        assert torch.equal(blk.call_many(coords.unsqueeze(-2), ii, jj, counts).squeeze(-1), many)
+        assert torch.equal(blk.call_many(coords[:, :5], ii[:5], jj[:5], [5]), parts[0])
+    with pytest.raises(RuntimeError):
+        blk.call_many(coords, ii, jj, [5, 1, 3])
+    # the third call (edges 6..8) against the oracle: every edge of a call samples with the offsets of the call's first edge
+    lo, hi = 6, 9
+    with torch.no_grad():
+        b2 = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+        b2(coords[:, lo:hi], ii[lo:hi], jj[lo:hi])
+        rows = [host(x[:1].float()).reshape(1, H, W, 7, 7, 2).copy() for x in b2.offset]
+    for lvl in range(4):
+        f1 = host(b2.pyramid[0][0][ii[lo:hi]].float())
+        f2 = host(b2.pyramid[lvl][0][jj[lo:hi]].float())
+        want, = oracle.lowMem_defSample(f1, f2, host(coords[0, lo:hi].unsqueeze(1) / 2 ** lvl), rows[lvl], 3)
+        got = host(many[0, lo:hi, lvl * 49:(lvl + 1) * 49]).reshape(want.shape)
+        assert np.abs(got - want).max() <= 1e-5, lvl
+
+
+@pytest.mark.gpu
+def test_sharded_altcorr_lookup_all_equals_lookup(lgu):
+    """ShardedAltCorr.lookup_all (one launch for all of a rank's chunks) against .lookup (chunk by chunk), world 1 and the
+    two halves of a world-2 partition; run_chunks(corr_all=...) hands every chunk its slice."""
+    torch.manual_seed(29)
+    N, C, H, W = 36, 64, 16, 24
+    fmaps = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    pairs = [(i, j) for i in range(N) for j in range(N) if i != j and abs(i - j) <= 2]
+    ii = torch.tensor([p[0] for p in pairs], device="cuda")
+    jj = torch.tensor([p[1] for p in pairs], device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, ii.numel(), H, W, 2, device="cuda")).contiguous()
+    with torch.no_grad():
+        for rank, world in ((0, 1), (0, 2), (1, 2)):
+            sac = lgu.sharded.ShardedAltCorr(ofsMap, ofsRes, None, fmaps, ii, jj, rank=rank, world=world)
+            idx, corr, counts = sac.lookup_all(coords)
+            loop = list(sac.lookup(coords))
+            assert counts == [int(i.numel()) for i, _ in loop] and len(counts) >= 2
+            assert torch.equal(idx, torch.cat([i for i, _ in loop]))
+            assert torch.equal(corr, torch.cat([c for _, c in loop], dim=1))
+            seen = []
+            lgu.sharded.run_chunks(sac.edges, ii, lambda i_, s_, c_: seen.append(c_) or (c_, c_, c_), corr_all=corr)
+            assert all(torch.equal(a, b) for a, (_, b) in zip(seen, loop))
