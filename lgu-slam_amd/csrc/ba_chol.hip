@@ -4,14 +4,18 @@
 // Reference: SparseBlock::solve (src/droid_kernels.cu:1206-1231) — Eigen SimplicialLLT on the HOST, in double, zero update
 // when the factorisation fails.  Round 1 / 2 used the library factorisation (rocSOLVER through torch.linalg.cholesky_ex):
 // 3.5 ms per iteration at 1194 x 1194, a chain of ~60 small unblocked-panel launches.  Here, per block column of 32:
-//   panel   every workgroup factorises the 32 x 32 diagonal block redundantly in LDS (no extra launch, no dependency on
-//           another workgroup), then solves 32 rows below it against the block, eight lanes per row;
-//   update  64 x 64 tiles of the trailing lower triangle, one workgroup each, panels staged in LDS.
+//   panel   every workgroup factorises the 32 x 32 diagonal block redundantly (no extra launch, no dependency on another
+//           workgroup) — ONE WAVE in registers, pivot columns broadcast with v_readlane, 1 / sqrt(pivot) from the hardware
+//           estimate + two Newton steps instead of a library root and 32 divisions — then solves 32 rows below it against
+//           the block, eight lanes per row;
+//   update  the trailing lower triangle on the double-precision matrix cores (v_mfma_f64_16x16x4_f64), one wave per
+//           16 x 64 block, operands from memory straight into the instruction's registers: no LDS, no barrier.
 // The right-hand side rides along as row n of the matrix, so the forward substitution is part of the factorisation;
-// the back substitution is one workgroup (column blocks from the last to the first, 1024 threads on the updates).
-// Measured at 1194 x 1194 (200 keyframes): panel launches 38 x 29 us — 26 of them the 32 barrier-paced pivots of the
-// diagonal block (double-precision root and divisions on the critical path), whatever the number of rows behind it —
-// updates 38 x 14 us, back substitution 0.32 ms: 2.1 ms per solve against 3.5 ms for the library.
+// the back substitution is one workgroup (column blocks from the last to the first, 1024 threads on the updates, the next
+// diagonal block in flight during the current one, the 32-step triangular solve of a block in one wave's registers).
+// Measured at 1194 x 1194 (200 keyframes, profiles/r02_ba_kernel_stats.csv): panel launches 38 x 13.5 us, updates
+// 38 x 7.3 us, back substitution 0.19 ms: 0.98 ms per solve (1.48 ms with LDS-staged 64 x 64 update tiles, library root /
+// divisions and LDS reads inside the two 32-step chains; 2.1 ms with barrier-paced pivots) against 3.5 ms for the library.
 // Parity: unpinned, like the rest of the bundle adjustment (the reference needs Eigen, absent here); held to an fp64
 // library solve in tests/test_ba.py.
 #include "lgu_common.hpp"
@@ -20,7 +24,6 @@ namespace lgu {
 
 constexpr int CH_NB = 32;    // block column width
 constexpr int CH_T = 256;    // threads of the panel / update kernels
-constexpr int CH_TILE = 64;  // trailing-update tile
 constexpr int CH_BT = 1024;  // threads of the back substitution
 
 // A[i][i] += ep + lm * A[i][i]  (L.diagonal() += ep + lm * L.diagonal(), :1213); row n := b; flag := 0
@@ -96,9 +99,13 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
 #pragma unroll
     for (int j = 0; j < CH_NB; j++) {
       double d = bcast(x[j], j);  // pivot (wave-uniform)
-      if (!(d > 0.0) || !(d < 1e300)) { bad = true; d = 1.0; }  // not positive definite: finish on a harmless pivot, x = 0 at the end
-      d = sqrt(d);
-      x[j] = i == j ? d : x[j] / d;  // column j: L_ij for i > j (rows above the diagonal carry don't-care values)
+      if (!(d > 1e-290) || !(d < 1e290)) { bad = true; d = 1.0; }  // not positive definite: finish on a harmless pivot, x = 0 at the end
+      // 1 / sqrt(d): the hardware estimate and two Newton steps (to the last bits of a double), then L_jj = d * r and
+      // L_ij = a_ij * r — the library root and division are ~50 dependent instructions per pivot on this critical path
+      double rs = __builtin_amdgcn_rsq(d);
+      rs = rs * __builtin_fma(-0.5 * d * rs, rs, 1.5);
+      rs = rs * __builtin_fma(-0.5 * d * rs, rs, 1.5);
+      x[j] = (i == j ? d : x[j]) * rs;  // column j: L_ij for i > j (rows above the diagonal carry don't-care values)
 #pragma unroll
       for (int k = j + 1; k < CH_NB; k++) x[k] = __builtin_fma(-x[j], bcast(x[j], k), x[k]);  // a_ik -= L_ij L_kj
     }
@@ -119,15 +126,26 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
   // rows behind the block: X L_kk^T = A_ik by forward substitution, EIGHT LANES PER ROW: lane l holds x_l, x_{l+8}, x_{l+16},
   // x_{l+24}; step j sums the products x_p L_jp (p < j) over the group with three DPP adds and the owner of column j takes
   // x_j = (a_j - sum) * (1 / L_jj).  (One thread per row was a chain of 496 LDS round trips: 39 us per launch.)
+  // (row j + 1 of the block is read from LDS while step j computes: the LDS round trip is off the 32-step chain)
+  double dn[4];
+#pragma unroll
+  for (int a = 0; a < 4; a++) dn[a] = D[0][8 * a + l];
 #pragma unroll
   for (int j = 0; j < CH_NB; j++) {
-    constexpr int dummy = 0; (void)dummy;
     const int aj = j >> 3, lj = j & 7;
+    double dc[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) dc[a] = dn[a];
+    if (j + 1 < CH_NB) {
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+        if (a <= ((j + 1) >> 3)) dn[a] = D[j + 1][8 * a + l];
+    }
     double s = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-      if (a < aj) s += x[a] * D[j][8 * a + l];
-      else if (a == aj) s += (l < lj) ? x[a] * D[j][8 * a + l] : 0.0;
+      if (a < aj) s += x[a] * dc[a];
+      else if (a == aj) s += (l < lj) ? x[a] * dc[a] : 0.0;
     }
     s = chol_sum8(s);
     const double v = (x[aj] - s) * dsq[j];
@@ -140,51 +158,73 @@ __global__ __launch_bounds__(CH_T) void chol_panel_kernel(double* A, double* ext
   }
 }
 
-// A[i][j] -= sum_t L[i][k0 + t] L[j][k0 + t] for the rows / columns behind the panel (rows include the right-hand side),
-// tiles on or below the diagonal.  Thread (ty, tx) owns a 4 x 4 sub-tile.
-__global__ __launch_bounds__(CH_T) void chol_update_kernel(double* A, double* ext, const double* __restrict__ stage, int n, int k0, int w) {
-  if (blockIdx.x > blockIdx.y) return;  // x = column tile, y = row tile
+// A[i][j] -= sum_t L[i][k0 + t] L[j][k0 + t] for the rows / columns behind the panel (rows include the right-hand side), on
+// or below the diagonal.  ONE WAVE per 16-row x 64-column block on the double-precision matrix cores
+// (v_mfma_f64_16x16x4_f64; layout found by tools/diag/mfma_f64_layout.hip: A lane = (row l % 16, k l / 16), B lane = (k l / 16,
+// column l % 16), D register r of lane l = (row 4 r + l / 16, column l % 16)): operands go from memory straight into the
+// registers the instruction reads — lane (i, q) takes the 64 contiguous bytes of columns k0 + 8 q .. + 7 of its row, and step
+// s multiplies element s of every lane (the order of the 32 products of a sum is free, A and B use the same one) — the
+// accumulators start as the tile itself and the panel enters negated, so there is no LDS, no barrier and no separate
+// read-modify-write pass.  (The 64 x 64 LDS-staged tiles this replaces took 14 us per launch, a chain of global -> LDS ->
+// barrier -> 256 LDS reads per thread -> read-modify-write; whole panels only: w == CH_NB.)
+typedef double chd4 __attribute__((ext_vector_type(4)));
+typedef double chd2 __attribute__((ext_vector_type(2)));
+constexpr int CH_UR = 16, CH_UC = 64;
+__global__ __launch_bounds__(kWave) void chol_update_kernel(double* A, double* ext, const double* __restrict__ stage, int n, int k0, int w) {
+  const int lane = threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0)  // the factor of the diagonal block, staged by the panel launch
-    for (int idx = threadIdx.x; idx < CH_NB * CH_NB; idx += CH_T) {
+    for (int idx = lane; idx < CH_NB * CH_NB; idx += kWave) {
       const int i = idx / CH_NB, j = idx - i * CH_NB;
       if (i < w && j <= i) A[(size_t)(k0 + i) * n + k0 + j] = stage[idx];
     }
-  __shared__ double Li[CH_TILE][CH_NB + 1], Lj[CH_TILE][CH_NB + 1];
   const int k1 = k0 + w;
-  const int i0 = k1 + blockIdx.y * CH_TILE, j0 = k1 + blockIdx.x * CH_TILE;
-  const int t = threadIdx.x;
-  for (int idx = t; idx < CH_TILE * CH_NB; idx += CH_T) {
-    const int r = idx / CH_NB, c = idx - r * CH_NB;
-    const int gi = i0 + r, gj = j0 + r;
-    Li[r][c] = (gi <= n && c < w) ? chol_row(A, ext, n, gi)[k0 + c] : 0.0;
-    Lj[r][c] = (gj < n && c < w) ? A[(size_t)gj * n + k0 + c] : 0.0;
-  }
-  __syncthreads();
-  const int ty = t / 16, tx = t % 16;
-  double acc[4][4];
+  const int i0 = k1 + blockIdx.y * CH_UR, j0 = k1 + blockIdx.x * CH_UC;  // y = row strip, x = column block
+  if (w != CH_NB || j0 > i0 + CH_UR - 1 || i0 > n) return;  // wave-uniform
+  const int li = lane & 15, q = lane >> 4;
+  double av[8], bv[4][8];
+  {
+    const int gi = i0 + li;
+    // 16-byte loads: n = 6 P is even, k0 a multiple of 32, A and ext 16-byte aligned (checked by the host entry)
+    const chd2* const ar = gi <= n ? reinterpret_cast<const chd2*>(chol_row(A, ext, n, gi) + k0 + 8 * q) : nullptr;
 #pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-#pragma unroll 4
-  for (int c = 0; c < CH_NB; c++) {
-    double li[4], lj[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) { li[a] = Li[ty * 4 + a][c]; lj[a] = Lj[tx * 4 + a][c]; }
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) acc[a][b] += li[a] * lj[b];
+    for (int s2 = 0; s2 < 4; s2++) {
+      const chd2 v = ar ? ar[s2] : chd2{0.0, 0.0};
+      av[2 * s2] = -v[0]; av[2 * s2 + 1] = -v[1];
+    }
   }
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
-    const int gi = i0 + ty * 4 + a;
-    if (gi > n) continue;
-    double* const rp = chol_row(A, ext, n, gi);
+  for (int jb = 0; jb < 4; jb++) {
+    const int gj = j0 + 16 * jb + li;
+    const chd2* const br = gj < n ? reinterpret_cast<const chd2*>(A + (size_t)gj * n + k0 + 8 * q) : nullptr;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int gj = j0 + tx * 4 + b;
-      if (gj < n && gj <= gi) rp[gj] -= acc[a][b];
+    for (int s2 = 0; s2 < 4; s2++) {
+      const chd2 v = br ? br[s2] : chd2{0.0, 0.0};
+      bv[jb][2 * s2] = v[0]; bv[jb][2 * s2 + 1] = v[1];
+    }
+  }
+  chd4 acc[4];
+  double* cp[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = i0 + 4 * r + q;
+    cp[r] = gi <= n ? chol_row(A, ext, n, gi) : nullptr;
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+      const int gj = j0 + 16 * jb + li;
+      acc[jb][r] = (cp[r] && gj < n && gj <= gi) ? cp[r][gj] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < 8; s2++)
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) acc[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[jb][s2], acc[jb], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = i0 + 4 * r + q;
+#pragma unroll
+    for (int jb = 0; jb < 4; jb++) {
+      const int gj = j0 + 16 * jb + li;
+      if (cp[r] && gj < n && gj <= gi) cp[r][gj] = acc[jb][r];
     }
   }
 }
@@ -203,19 +243,37 @@ __global__ __launch_bounds__(CH_BT) void chol_backsolve_kernel(const double* __r
   for (int i = t; i < n; i += CH_BT) ys[i] = ext[i];
   __syncthreads();
   const int nblk = (n + CH_NB - 1) / CH_NB;
+  static_assert(CH_BT == CH_NB * CH_NB, "one thread per entry of a diagonal block");
+  const int di = t / CH_NB, dj = t - di * CH_NB;
+  auto diag_entry = [&](int kb) {  // this thread's entry of diagonal block kb
+    const int k0 = kb * CH_NB, w = n - k0 < CH_NB ? n - k0 : CH_NB;
+    return (di < w && dj <= di) ? A[(size_t)(k0 + di) * n + k0 + dj] : 0.0;
+  };
+  double nd = diag_entry(nblk - 1);
   for (int kb = nblk - 1; kb >= 0; kb--) {
     const int k0 = kb * CH_NB, w = n - k0 < CH_NB ? n - k0 : CH_NB;
-    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_BT) {
-      const int i = idx / CH_NB, j = idx - i * CH_NB;
-      Dk[i * (CH_NB + 1) + j] = (i < w && j <= i) ? A[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-    }
+    Dk[di * (CH_NB + 1) + dj] = nd;
     __syncthreads();
+    if (kb > 0) nd = diag_entry(kb - 1);  // the next block travels during this block's solve and update
     if (t < kWave) {  // one wave: x_j = (y_j - sum_{i > j} L_ij x_i) / L_jj, j descending; lane i holds the running y_i
       double v = t < w ? ys[k0 + t] : 0.0;
-      for (int j = w - 1; j >= 0; j--) {
-        const double xj = __shfl(v, j, kWave) / Dk[j * (CH_NB + 1) + j];
-        if (t == j) v = xj;
-        else if (t < j) v -= Dk[j * (CH_NB + 1) + t] * xj;
+      const double rinv = t < w ? 1.0 / Dk[t * (CH_NB + 1) + t] : 0.0;  // one division per lane, off the 32-step chain
+      auto bcast = [](double q, int src) {  // src is wave-uniform: v_readlane, not a trip through the LDS crossbar
+        const long long bits = __builtin_bit_cast(long long, q);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)bits, src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), src);
+        return __builtin_bit_cast(double, ((long long)hi << 32) | lo);
+      };
+      // column t of the block in registers before the chain starts (rows past w hold zeros and identity pivots do no harm:
+      // their v is 0), so a step is four v_readlane, a multiplication and an FMA with no LDS round trip
+      double lcol[CH_NB];
+      const int tc = t & (CH_NB - 1);
+#pragma unroll
+      for (int j = 0; j < CH_NB; j++) lcol[j] = Dk[j * (CH_NB + 1) + tc];
+#pragma unroll
+      for (int j = CH_NB - 1; j >= 0; j--) {
+        const double xj = bcast(v, j) * bcast(rinv, j);
+        v = t == j ? xj : (t < j ? __builtin_fma(-lcol[j], xj, v) : v);
       }
       if (t < w) { xb[t] = v; ys[k0 + t] = v; }
     }
@@ -254,6 +312,7 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
   if (!A || !b || !x || !work || P < 1) return LGU_E_BADARG;
   const int n = 6 * P;
   if (n > 16000) return LGU_E_UNSUPPORTED;  // the back substitution keeps the right-hand side in LDS
+  if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(work)) & 15) != 0) return LGU_E_BADARG;  // 16-byte operand loads
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   double* ext = work;
   int* flag = reinterpret_cast<int*>(work + n);
@@ -268,8 +327,8 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
     const int w = n - k0 < CH_NB ? n - k0 : CH_NB;
     const int rows = n + 1 - (k0 + w);  // rows behind the block, the right-hand side included
     hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_RPW - 1) / CH_RPW), dim3(CH_T), 0, st, A, ext, stage, flag, n, k0);
-    const int nt = (rows + CH_TILE - 1) / CH_TILE;
-    hipLaunchKernelGGL(chol_update_kernel, dim3(nt, nt), dim3(CH_T), 0, st, A, ext, stage, n, k0, w);
+    hipLaunchKernelGGL(chol_update_kernel, dim3((rows + CH_UC - 1) / CH_UC, (rows + CH_UR - 1) / CH_UR), dim3(kWave), 0, st, A, ext,
+                       stage, n, k0, w);
   }
   const size_t lds = sizeof(double) * ((size_t)n + CH_NB * (CH_NB + 1) + CH_NB);
   hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(CH_BT), lds, st, A, ext, flag, x, n);
