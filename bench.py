@@ -525,7 +525,12 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
         tg = target.permute(0, 3, 1, 2).contiguous()                          # :295-296
         wg = weight.permute(0, 3, 1, 2).contiguous()
         poses.copy_(poses0); disps.copy_(disps0)
-        lgu.ba.ba(poses, disps, intr, sens, tg, wg, eta, ii, jj, 1, N, 2, 1e-5, 1e-2, False)   # :299-300
+        if args.ba_split:   # owners build / eliminate their edges and depth frames, the system is all-reduced, the solve replicated
+            tl = torch.cat(local[0], 0).permute(0, 3, 1, 2).contiguous() if local[0] else tg[:0]
+            wl = torch.cat(local[1], 0).permute(0, 3, 1, 2).contiguous() if local[1] else wg[:0]
+            sh.sharded_ba_split(edges, tl, wl, poses, disps, intr, sens, 0.2 * damping + 1e-7, ii, jj, 1, N, 2, 1e-5, 1e-2, False)
+        else:
+            lgu.ba.ba(poses, disps, intr, sens, tg, wg, eta, ii, jj, 1, N, 2, 1e-5, 1e-2, False)   # :299-300
         ev[3].record()
         if record:
             ev[3].synchronize()
@@ -567,7 +572,8 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                          "units_per_step": units, "update_operator": "stand-in (out of scope)",
                          "lookups": "one launch for all of the rank's chunks (AltCorrBlock.call_many: every chunk's results bit-identical "
                                     "to its own call)" if one_launch else "one call per chunk (--chunk-loop: the reference's loop)",
-                         "ba": "lgu_slam_amd.ba (experimental: parity unpinned)"},
+                         "ba": "lgu_slam_amd.ba (experimental: parity unpinned); " + ("per-edge work on the owners, all-reduced system, replicated solve "
+                                "(--ba-split)" if args.ba_split else "replicated on every rank")},
               "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2],
                                            "corr_block_per_step": ph[3]},
               "phases_note": "lookups / exchange / ba: medians over the timed steps; corr_block_per_step: MEAN over the timed steps of "
@@ -642,6 +648,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--chunk-loop", action="store_true", help="backend workload: one lookup call per source-frame chunk, as the "
                     "reference's update_lowmem issues them, instead of ONE launch for all of the rank's chunks (the default; same results)")
+    ap.add_argument("--ba-split", action="store_true", help="backend workload: bundle adjustment with the per-edge work on the edges' "
+                    "owners + an all-reduce of the reduced camera system (sharded.sharded_ba_split) instead of replicated on every rank")
     ap.add_argument("--no-graph", action="store_true", help="issue the timed steps one by one from Python instead of replaying "
                                                              "them from one HIP graph")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")

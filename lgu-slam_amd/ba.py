@@ -160,7 +160,7 @@ def _plan_for(lib, ii, jj, t0, t1, motion_only, dev):
 
 
 def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v, ii, jj, t0, t1, iterations, lm, ep,
-         motion_only):
+         motion_only, hooks=None):
     """The iterations of one call on the current stream.  (Capturable when the window fits the LDS solver; replaying a
     whole frontend-sized call as one HIP graph was measured and gives nothing — 0.59 ms either way: the call is bound
     by its kernels, not by its ~40 launches.)"""
@@ -178,21 +178,23 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
         K = pl.K
         Q = torch.empty((K, HW), dtype=f32, device=dev)
         w = torch.empty((K, HW), dtype=f32, device=dev)
-    Hs = torch.empty((4, E, 6, 6), dtype=f32, device=dev)
-    vs = torch.empty((2, E, 6), dtype=f32, device=dev)
-    Eii = torch.empty((E, 6, HW), dtype=f32, device=dev)
+    reduce_system, after_depth = hooks if hooks is not None else (None, None)   # sharded.sharded_ba_split
+    Hs = torch.empty((4, max(E, 1), 6, 6), dtype=f32, device=dev)   # (a rank of a split BA may own no edge: E = 0)
+    vs = torch.empty((2, max(E, 1), 6), dtype=f32, device=dev)
+    Eii = torch.empty((max(E, 1), 6, HW), dtype=f32, device=dev)[:E]
     Eall = torch.empty((P + E, 6, HW), dtype=f32, device=dev)   # E = cat(Ei, Eij) (:1401) without the copy:
     Eij = Eall[P:]                                               # the build kernel writes Eij in place, Ei is summed into the head
     scratch = torch.empty((max(E, 1) * lib.lgu_ba_build_slices(E) * 90,), dtype=f32, device=dev)
-    Cii = torch.empty((E, HW), dtype=f32, device=dev)
-    wi = torch.empty((E, HW), dtype=f32, device=dev)
+    Cii = torch.empty((max(E, 1), HW), dtype=f32, device=dev)[:E]
+    wi = torch.empty((max(E, 1), HW), dtype=f32, device=dev)[:E]
     dx = torch.zeros((P, 6), dtype=f32, device=dev)
     dz = None
     for _ in range(iterations):
-        _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
-                                        _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
-                                        st),
-                   "ba build")
+        if E:
+          _lib.check(lib.lgu_ba_build_f32(_ptr(targets), _ptr(weights), _ptr(poses), _ptr(disps), _ptr(intrinsics), _ptr(ii),
+                                          _ptr(jj), _ptr(Hs), _ptr(vs), _ptr(Eii), _ptr(Eij), _ptr(Cii), _ptr(wi), _ptr(scratch), E, ht, wd,
+                                          st),
+                     "ba build")
         S = sv = None
         if not motion_only:
             _lib.check(lib.lgu_ba_depth_system_f32(_ptr(Cii), _ptr(wi), _ptr(acc_ii_kx.ptrs), _ptr(acc_ii_kx.cols), _ptr(kx), _ptr(disps),
@@ -214,6 +216,8 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
                                            _ptr(vs), _ptr(pl.csr_v[0]), _ptr(pl.csr_v[1]),
                                            _ptr(sv) if sv is not None else None, _ptr(cs[0]) if cs else None, _ptr(cs[1]) if cs else None,
                                            _ptr(Ad), _ptr(b), P, st), "ba assembly")
+        if reduce_system is not None:   # split BA: every rank assembled its own edges' part of the system
+            reduce_system(Ad, b)
         dx = torch.empty((P, 6), dtype=f32, device=dev)
         rc = lib.lgu_ba_solve_f64(_ptr(Ad), _ptr(b), _ptr(dx), P, float(lm), float(ep), st)   # one workgroup, matrix in LDS
         if rc == _lib.LGU_E_UNSUPPORTED:   # more than 32 poses in the window: blocked Cholesky over the matrix in HBM (csrc/ba_chol.hip)
@@ -231,13 +235,19 @@ def _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v,
             dz = torch.empty((K, HW), dtype=f32, device=dev)
             _lib.check(lib.lgu_ba_depth_update_f32(_ptr(Q), _ptr(w), _ptr(dw), _ptr(acc_exp_kx.ptrs), _ptr(acc_exp_kx.cols), _ptr(kx),
                                                    _ptr(dz), _ptr(disps), K, HW, st), "ba depth update")  # :1415, :933-946
+            if after_depth is not None:   # split BA: the owners' rows of disps replace this rank's partial ones
+                after_depth(disps)
         _lib.check(lib.lgu_ba_pose_retr_f32(_ptr(poses), _ptr(dx), t0, t1, st), "ba pose retraction")
     return [dx, dz]
 
 
-def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only):
-    _check(poses, "poses", disps, "disps", intrinsics, "intrinsics", disps_sens, "disps_sens", targets, "targets",
-           weights, "weights")
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only, _hooks=None):
+    """`_hooks` (sharded.sharded_ba_split only): (reduce_system(Ad, b), after_depth(disps)) called once per iteration, and
+    `eta` may then be a callable kx -> (K, ht, wd) giving the damping rows of this call's depth frames."""
+    named = [poses, "poses", disps, "disps", intrinsics, "intrinsics", disps_sens, "disps_sens"]
+    if ii.numel():   # (a rank of a split BA may own no edge)
+        named += [targets, "targets", weights, "weights"]
+    _check(*named)
     _check_dtype(ii, "ii", torch.int64)
     _check_dtype(jj, "jj", torch.int64)
     lib = _lib.load()
@@ -248,8 +258,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
         pl = _plan_for(lib, ii, jj, t0, t1, motion_only, dev)
         eta_v = None
         if not motion_only:
+            if callable(eta):
+                eta = eta(pl.kx)
             eta_v = eta.reshape(-1, HW).to(torch.float32).contiguous()
             if eta_v.shape[0] not in (1, pl.K):
                 raise RuntimeError("ba: eta must have one row per depth frame (%d) or one row, got %d" % (pl.K, eta_v.shape[0]))
         return _run(pl, lib, poses, disps, intrinsics, disps_sens, targets, weights, eta_v, ii, jj, t0, t1, iterations, lm, ep,
-                    motion_only)
+                    motion_only, _hooks)
