@@ -1881,3 +1881,43 @@ def test_sharded_altcorr_lookup_all_equals_lookup(lgu):
             seen = []
             lgu.sharded.run_chunks(sac.edges, ii, lambda i_, s_, c_: seen.append(c_) or (c_, c_, c_), corr_all=corr)
             assert all(torch.equal(a, b) for a, (_, b) in zip(seen, loop))
+
+
+@pytest.mark.gpu
+def test_config5_shard_in_one_launch_equals_the_chunk_loop(lgu, oracle):
+    """BASELINE config 5's per-GPU shard at full size (rank 0 of 8 over a 200-keyframe graph of 60x80x128 half maps, edges
+    at most 5 frames apart: ~250 edges in 4 source-frame chunks): ShardedAltCorr.lookup_all — ONE lookup launch with
+    per-edge offset rows — against the reference's chunk loop, bit for bit, and the first edge of the LAST chunk against
+    the C oracle's lowMem_defSample over that chunk's first-edge offsets."""
+    torch.manual_seed(31)
+    N, C, H, W, span = 200, 128, 60, 80, 5
+    fmaps = (torch.randn(1, N, C, H, W, device="cuda") * 0.5).half()
+    ofsMap = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(2 * C, 98, 3, padding=1).cuda()
+    pairs = [(i, j) for i in range(N) for j in range(N) if i != j and abs(i - j) <= span]
+    ii = torch.tensor([p[0] for p in pairs], device="cuda")
+    jj = torch.tensor([p[1] for p in pairs], device="cuda")
+    sac = lgu.sharded.ShardedAltCorr(ofsMap, ofsRes, None, fmaps, ii, jj, rank=0, world=8)
+    own = sac.edges.my_edges
+    assert 200 <= own.numel() <= 300 and len(sac.edges.my_chunks) >= 3
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = torch.zeros(1, ii.numel(), H, W, 2, device="cuda")
+    coords[:, own] = torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, own.numel(), H, W, 2, device="cuda")
+    with torch.no_grad():
+        idx, corr, counts = sac.lookup_all(coords)
+        assert getattr(sac.block, "_calls_key", None) is not None
+        pos = 0
+        for cidx, c in sac.lookup(coords):
+            assert torch.equal(corr[:, pos:pos + cidx.numel()], c)
+            pos += cidx.numel()
+        assert pos == own.numel() and torch.isfinite(corr).all()
+        last = sac.edges.my_chunks[-1]
+        rows = [host(x[:1].float()).reshape(1, H, W, 7, 7, 2).copy() for x in sac.block.offset]   # the last call's, materialised
+    e = int(last[0])
+    s = own.numel() - last.numel()
+    for lvl in range(4):
+        f1 = host(sac.block.pyramid[0][0][ii[e]].float())[None]
+        f2 = host(sac.block.pyramid[lvl][0][jj[e]].float())[None]
+        want, = oracle.lowMem_defSample(f1, f2, host(coords[0, e][None, None] / 2 ** lvl), rows[lvl], 3)
+        got = host(corr[0, s, lvl * 49:(lvl + 1) * 49]).reshape(want.shape)
+        assert np.abs(got - want).max() <= 1e-5, lvl
