@@ -3,7 +3,7 @@
 
 extern "C" {
 
-const char* lgu_version(void) { return "lgu_corr 0.5.0 gfx950"; }
+const char* lgu_version(void) { return "lgu_corr 0.6.0 gfx950"; }
 
 const char* lgu_error_string(int code) {
   switch (code) {

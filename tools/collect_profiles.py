@@ -105,6 +105,8 @@ def load(name):
 b = load("bench.json")
 bl = load("bench_lowmem.json")
 bb = load("bench_backend.json")
+bb_loop = load("bench_backend_loop.json") if os.path.exists(os.path.join(G, "bench_backend_loop.json")) else None
+bb_split = load("bench_backend_split.json") if os.path.exists(os.path.join(G, "bench_backend_split.json")) else None
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))] if os.path.exists(os.path.join(G, "compare_ref.jsonl")) else None
 import shutil
 for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_calls.json", "%s_e2e_glue_calls.json"),
@@ -138,6 +140,7 @@ json.dump({"note": "tools/gpu_full_run.sh on one MI355X box: default bench.py li
                    "and PMC traffic of the metric kernel in cold mode for both pyramid layouts, low-memory kernel trace, comparison "
                    "with the reference kernels (oracle/_ref) on the same device",
            "bench": b, "bench_lowmem_config4": bl, "bench_backend_config5_n1": bb,
+           "bench_backend_config5_n1_chunk_loop": bb_loop, "bench_backend_config5_n1_ba_split": bb_split,
            "kernel_stats_defcorr_tiled": dict(kern_t), "kernel_stats_defcorr_rowmajor": dict(kern_r),
            "traffic_tiled": traffic_t, "traffic_rowmajor": traffic_r, "lowmem_kernels": lowmem, "compare_ref": cmp_},
           open(os.path.join(P, "%s_final.json" % tag), "w"), indent=1)

@@ -18,6 +18,8 @@ timeout -k 10 500 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.er
 cut -c1-1500 gpurun_out/bench.json
 timeout -k 10 300 python bench.py --workload lowmem --edges 16 > gpurun_out/bench_lowmem.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --workload backend --steps 16 --warmup 8 > gpurun_out/bench_backend.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --workload backend --steps 16 --warmup 8 --chunk-loop > gpurun_out/bench_backend_loop.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --workload backend --steps 16 --warmup 8 --ba-split > gpurun_out/bench_backend_split.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/ab_cold.py 0,7,6 6 tiled,rowmajor 0,1 > gpurun_out/ab_final.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/ab_final.jsonl
 timeout -k 10 300 python tools/ab_lowmem.py 1,1:c,2:c > gpurun_out/ab_lowmem.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
@@ -25,7 +27,7 @@ timeout -k 10 300 python tools/e2e_calls.py > gpurun_out/e2e_calls.json 2> gpuru
 { timeout -k 10 200 python tools/prof_init.py 20 f32 && timeout -k 10 200 python tools/prof_init.py 20 half; } 2> gpurun_out/bench.err | grep "CorrBlock.__init__" > gpurun_out/prof_init.txt || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/prof_init.txt
 python -c "import json
-for n in ('bench_lowmem','bench_backend'):
+for n in ('bench_lowmem','bench_backend','bench_backend_loop','bench_backend_split'):
     d=json.load(open('gpurun_out/%s.json'%n)); print(n,'value',round(d['value'],1),'ms',round(d['ms_per_step'],4), d.get('phases_ms_max_over_ranks'))"
 rm -rf gpurun_out/prof_trace* gpurun_out/prof_fetch* gpurun_out/prof_write* gpurun_out/prof_lm
 cd /tmp
