@@ -404,7 +404,9 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
 /* lgu_ba_assemble_f64: the four scatter sums of one iteration, their zero-fills and the blocked -> dense permutation in one
  * launch: block d = bi * P + bj of the system = sum of Hs rows [hptr[d], hptr[d+1]) of hidx - sum of S rows (sptr, sidx;
  * S may be NULL: motion only), written to Ad (6P x 6P row-major, double); b (6P) likewise from vs / sv.  CSR tables cover
- * all P*P (resp. P) destinations.  Per-entry arithmetic and summation order are those of lgu_ba_scatter_sum_f64. */
+ * all P*P (resp. P) destinations.  An entry e < 0 of sidx stands for row -e - 1 of S TRANSPOSED (S_ca = S_ac^T: the caller
+ * computes the Schur products for a <= c only); direct entries first in a segment.  Per-entry arithmetic and summation
+ * order are those of lgu_ba_scatter_sum_f64 (direct rows, then transposed rows). */
 int lgu_ba_assemble_f64(const float* Hs, const long long* hptr, const long long* hidx, const float* S, const long long* sptr,
                         const long long* sidx, const float* vs, const long long* vptr, const long long* vidx, const float* sv,
                         const long long* svptr, const long long* svidx, double* Ad, double* b, int P, void* stream);

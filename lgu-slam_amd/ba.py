@@ -125,17 +125,27 @@ class _Plan:
         ent = ent[np.argsort(kk_h[ent], kind="stable")]
         _, starts, sizes = np.unique(kk_h[ent], return_index=True, return_counts=True)
         a_l, c_l, k_l = [], [], []
-        for s0, m_ in zip(starts, sizes):                      # one small outer product per depth frame
-            g = ent[s0:s0 + m_]
-            a_l.append(np.repeat(g, m_)); c_l.append(np.tile(g, m_))
-            k_l.append(np.full(m_ * m_, kk_h[g[0]], np.int64))
+        for s0, m_ in zip(starts, sizes):                      # one small outer product per depth frame, upper triangle:
+            g = ent[s0:s0 + m_]                                # S_ca = S_ac^T is read transposed by the assembly
+            ua, uc = np.triu_indices(m_)
+            a_l.append(g[ua]); c_l.append(g[uc])
+            k_l.append(np.full(len(ua), kk_h[g[0]], np.int64))
         self.have_pairs = len(a_l) > 0
         if self.have_pairs:
             a_n, c_n, k_n = np.concatenate(a_l), np.concatenate(c_l), np.concatenate(k_l)
         else:
             a_n = c_n = k_n = np.zeros(1, np.int64)
         self.trip_t = torch.from_numpy(np.ascontiguousarray(np.stack([a_n, c_n, k_n], 1))).to(dev)
-        self.csr_S = _csr((jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0), P * P, dev) if self.have_pairs else None
+        if self.have_pairs:
+            # destinations of S_ac (block (pose of a, pose of c)) and, for a != c, of its transpose (block (pose of c, pose of
+            # a)); lgu_ba_assemble_f64 takes the transposed rows as negative indices -row - 1
+            npair = len(a_n)
+            d_ac = (jj_exp_h[a_n] - t0) * P + (jj_exp_h[c_n] - t0)
+            d_ca = np.where(a_n != c_n, (jj_exp_h[c_n] - t0) * P + (jj_exp_h[a_n] - t0), -1)
+            ptr, idx = _csr(np.concatenate([d_ac, d_ca]), P * P, dev)
+            self.csr_S = (ptr, torch.where(idx < npair, idx, npair - 1 - idx))
+        else:
+            self.csr_S = None
         self.csr_sv = _csr(jj_exp_h - t0, P, dev)
         self.jpose = torch.from_numpy(jj_exp_h - t0).to(dev).contiguous()
         self.acc_ii_kx = _Accum(lib, ii_h, kx_h, dev)

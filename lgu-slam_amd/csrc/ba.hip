@@ -297,9 +297,19 @@ __global__ __launch_bounds__(BA_THREADS) void ba_assemble_kernel(const float* __
     double out = 0.0;
     if (hptr[d + 1] > hptr[d]) out += 1.0 * a;
     if (S) {
-      double c = 0.0;
-      for (long long i = sptr[d]; i < sptr[d + 1]; i++) c += (double)S[(size_t)sidx[i] * 36 + k];
-      if (sptr[d + 1] > sptr[d]) out += -1.0 * c;
+      // entries e >= 0: row e of S as it is; e < 0: row -e - 1 TRANSPOSED (S_ca = S_ac^T: the Schur products are computed for
+      // a <= c only).  Direct rows come first in a segment (the tables are built that way) and the two kinds are summed
+      // apart, as two scatter-sum passes would
+      double c = 0.0, ct = 0.0;
+      bool anyd = false, anyt = false;
+      const int kt = (k % 6) * 6 + k / 6;
+      for (long long i = sptr[d]; i < sptr[d + 1]; i++) {
+        const long long e = sidx[i];
+        if (e >= 0) { c += (double)S[(size_t)e * 36 + k]; anyd = true; }
+        else { ct += (double)S[(size_t)(-e - 1) * 36 + kt]; anyt = true; }
+      }
+      if (anyd) out += -1.0 * c;
+      if (anyt) out += -1.0 * ct;
     }
     const int bi = d / P, bj = d - bi * P, r = k / 6, cidx = k - r * 6;
     Ad[((size_t)bi * 6 + r) * (6 * P) + bj * 6 + cidx] = out;

@@ -320,6 +320,10 @@ def test_fused_assembly_equals_the_scatter_sum_composition(lgu, motion_only):
         S = torch.randn(trip.shape[0], 36, device="cuda", generator=g)
         sv = torch.randn(P + E, 6, device="cuda", generator=g)
         B._ScatterSum(lib, (jj_exp[trip[:, 0]] - t0) * P + (jj_exp[trip[:, 1]] - t0), "cuda")(S, A, -1.0, st)
+        # the plan lists the pairs a <= c of a depth frame only: block (c, a) is the transpose of block (a, c)
+        assert (trip[:, 0] <= trip[:, 1]).all() and (trip[:, 0] < trip[:, 1]).any()
+        St = S.view(-1, 6, 6).transpose(1, 2).reshape(-1, 36).contiguous()
+        B._ScatterSum(lib, np.where(trip[:, 0] != trip[:, 1], (jj_exp[trip[:, 1]] - t0) * P + (jj_exp[trip[:, 0]] - t0), -1), "cuda")(St, A, -1.0, st)
         B._ScatterSum(lib, jj_exp - t0, "cuda")(sv, b, -1.0, st)
     want = A.view(P, P, 6, 6).permute(0, 2, 1, 3).reshape(6 * P, 6 * P).contiguous()
     Ad = torch.full((6 * P, 6 * P), 7.0, dtype=torch.float64, device="cuda")
