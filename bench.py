@@ -505,6 +505,7 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
     # INSIDE the timed region: a step carries an eighth of it on average (phase "corr_block" = mean over the timed steps).
     CALL_STEPS = 8
     it_no = [0]
+    step_wall = []
 
     def step(record):
         ev[4].record()
@@ -537,6 +538,7 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
             for k, name in enumerate(("lookups", "exchange", "ba")):
                 phase[name].append(ev[k].elapsed_time(ev[k + 1]))
             phase["corr_block"].append(ev[4].elapsed_time(ev[0]))
+            step_wall.append(time.perf_counter())
 
     def barrier():
         if use_dist:
@@ -580,6 +582,7 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                              "the AltCorrBlock construction (pyramid) that every %d-th iteration starts with, as one update_lowmem "
                              "call = one block + 8 iterations in the reference; the first iteration over a new block also pays the "
                              "per-frame partial convolutions of the offset heads inside its lookups" % CALL_STEPS,
+              "step_wall_ms_this_rank": [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + step_wall[:-1], step_wall)],
               "replicas_agree": agree,
               "roofline": None, "cpu_baseline": None})
     if use_dist:
