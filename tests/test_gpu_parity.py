@@ -1921,3 +1921,47 @@ def test_config5_shard_in_one_launch_equals_the_chunk_loop(lgu, oracle):
         want, = oracle.lowMem_defSample(f1, f2, host(coords[0, e][None, None] / 2 ** lvl), rows[lvl], 3)
         got = host(corr[0, s, lvl * 49:(lvl + 1) * 49]).reshape(want.shape)
         assert np.abs(got - want).max() <= 1e-5, lvl
+
+
+@pytest.mark.gpu
+def test_lowmem_pyramid_offset_rows_per_edge(lgu, oracle):
+    """lgu_lowmem_pyramid_calls_fwd_h16 at the operator level: every edge samples with the offset row `off_row` names — an
+    arbitrary (non-monotonic) edge -> row table — and equals, bit for bit, the ordinary launch over that edge alone with
+    that row as its offsets; one edge against the C oracle; rows past the tensors are clamped on the device (no wild
+    read); argument checks."""
+    torch.manual_seed(41)
+    B, H, W, C, L, K = 11, 16, 24, 64, 4, 3
+    f1 = (torch.randn(B, H, W, C, device="cuda") * 0.125).half()
+    f2s = [(torch.randn(B, H >> l, W >> l, C, device="cuda") * 0.125).half() for l in range(L)]
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda").float(), torch.arange(W, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None] + 3 * torch.randn(B, 1, H, W, 2, device="cuda")).contiguous()
+    o0 = (4 * torch.tanh(torch.randn(K, H, W, 7, 7, 2, device="cuda"))).contiguous()
+    o1 = ((4 * torch.tanh(torch.randn(K, H, W, 7, 7, 2, device="cuda")) + o0) / 2).contiguous()
+    rows = torch.tensor([2, 0, 1, 1, 2, 0, 0, 2, 1, 0, 2], dtype=torch.int32, device="cuda")
+    out = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0.clone(), o1.clone(), None, None], 3, off_row=rows)
+    assert out.shape == (B, 1, L * 49, H, W)
+    for b in range(B):
+        r = int(rows[b])
+        one = lgu.ops.lowmem_pyramid_forward_mixed(f1[b:b + 1].contiguous(), [f[b:b + 1].contiguous() for f in f2s],
+                                                   coords[b:b + 1].contiguous(),
+                                                   [o0[r:r + 1].clone(), o1[r:r + 1].clone(), None, None], 3)
+        assert torch.equal(out[b:b + 1], one), b
+    b, r = 4, 2
+    for l, off in enumerate((o0, o1, None, None)):
+        o_np = host(off[r:r + 1]).copy() if off is not None else np.zeros((1, H, W, 7, 7, 2), np.float32)
+        want, = oracle.lowMem_defSample(host(f1[b:b + 1].float()), host(f2s[l][b:b + 1].float()), host(coords[b:b + 1] / 2 ** l),
+                                        o_np, 3)
+        assert np.abs(host(out[b:b + 1, :, l * 49:(l + 1) * 49]).reshape(want.shape) - want).max() <= 1e-5, l
+    # out-of-range rows: clamped to [0, K) on the device
+    wild = rows.clone(); wild[3] = 1000; wild[5] = -7
+    got = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0.clone(), o1.clone(), None, None], 3, off_row=wild)
+    ref = rows.clone(); ref[3] = K - 1; ref[5] = 0
+    assert torch.equal(got, lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0.clone(), o1.clone(), None, None], 3, off_row=ref))
+    with pytest.raises(RuntimeError):   # one int32 entry per edge
+        lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0, o1, None, None], 3, off_row=rows[:5].contiguous())
+    with pytest.raises(RuntimeError):
+        lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o0, o1, None, None], 3, off_row=rows.long())
+    with pytest.raises(RuntimeError):   # half feature maps only
+        lgu.ops.lowmem_pyramid_forward_mixed(f1.float(), [f.float() for f in f2s], coords, [o0, o1, None, None], 3, off_row=rows)
+    with pytest.raises(RuntimeError):   # one sample per pixel
+        lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords.repeat(1, 2, 1, 1, 1).contiguous(), [o0, o1, None, None], 3, off_row=rows)
