@@ -487,6 +487,7 @@ class AltCorrBlock:
                                                      chunked=True, off_row=off_row)
         except _lib.UnsupportedShape:
             return one_by_one()
+        self.one_launch_calls = getattr(self, "one_launch_calls", 0) + 1   # (tests: the one-launch path ran, not the loop)
         sl, nl = starts[-1], counts[-1]
         il, jl, cl = iic[sl:], jjc[sl:], c0[sl:]
         self._offset, self._zero_level = None, zero_level

@@ -1822,7 +1822,7 @@ def test_altcorrblock_call_many_equals_the_calls_one_by_one(lgu, oracle, shape):
     with torch.no_grad():
         blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
         many = blk.call_many(coords, ii, jj, counts)
-        assert getattr(blk, "_calls_key", None) is not None        # the one-launch path ran, not the fallback loop
+        assert getattr(blk, "one_launch_calls", 0) == 1             # the one-launch path ran, not the fallback loop
         off_many = [o.clone() for o in blk.offset]
         ref_blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
         parts, s = [], 0
@@ -1874,6 +1874,7 @@ def test_sharded_altcorr_lookup_all_equals_lookup(lgu):
         for rank, world in ((0, 1), (0, 2), (1, 2)):
             sac = lgu.sharded.ShardedAltCorr(ofsMap, ofsRes, None, fmaps, ii, jj, rank=rank, world=world)
             idx, corr, counts = sac.lookup_all(coords)
+            assert sac.block.one_launch_calls == 1
             loop = list(sac.lookup(coords))
             assert counts == [int(i.numel()) for i, _ in loop] and len(counts) >= 2
             assert torch.equal(idx, torch.cat([i for i, _ in loop]))
@@ -1905,7 +1906,7 @@ def test_config5_shard_in_one_launch_equals_the_chunk_loop(lgu, oracle):
     coords[:, own] = torch.stack([xs, ys], -1)[None, None] + 2.0 * torch.randn(1, own.numel(), H, W, 2, device="cuda")
     with torch.no_grad():
         idx, corr, counts = sac.lookup_all(coords)
-        assert getattr(sac.block, "_calls_key", None) is not None
+        assert getattr(sac.block, "one_launch_calls", 0) == 1
         pos = 0
         for cidx, c in sac.lookup(coords):
             assert torch.equal(corr[:, pos:pos + cidx.numel()], c)
