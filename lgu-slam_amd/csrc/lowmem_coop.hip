@@ -72,24 +72,26 @@ struct CoParams {
   int n_orow;
 };
 
-// the four corner dots of one tap straight from memory (boxes larger than the patch)
-__device__ __noinline__ float4 co_corner_dots(const _Float16* f1p, const _Float16* F2, ptrdiff_t pos11, int C, int W2, int mask,
-                                              ptrdiff_t pstride, ptrdiff_t cstride) {
-  float q11 = 0.f, q21 = 0.f, q12 = 0.f, q22 = 0.f;
-  auto dot = [](const cohalf8& f, const cohalf8& a, float s) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
-    return s;
-  };
+// one corner dot of one tap straight from memory (boxes larger than the patch): channels in order, as the reference sums
+// them.  One corner per call and not inlined: the rare path must not set the register count of the sampling phase.
+__device__ __noinline__ float co_corner_dot(const _Float16* f1p, const _Float16* f2p, int C, ptrdiff_t cstride) {
+  float s = 0.f;
   for (int c = 0; c < C; c += 8) {
     const cohalf8 f = *reinterpret_cast<const cohalf8*>(f1p + c);
-    const _Float16* base = F2 + (ptrdiff_t)(c / 8) * cstride;
-    if (mask & 1) q11 = dot(f, *reinterpret_cast<const cohalf8*>(base + pos11 * pstride), q11);
-    if (mask & 2) q21 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + 1) * pstride), q21);
-    if (mask & 4) q12 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + W2) * pstride), q12);
-    if (mask & 8) q22 = dot(f, *reinterpret_cast<const cohalf8*>(base + (pos11 + W2 + 1) * pstride), q22);
+    const cohalf8 a = *reinterpret_cast<const cohalf8*>(f2p + (ptrdiff_t)(c / 8) * cstride);
+#pragma unroll
+    for (int i = 0; i < 8; i++) s = __builtin_fmaf((float)f[i], (float)a[i], s);
   }
-  return make_float4(q11, q21, q12, q22);
+  return s;
+}
+__device__ __forceinline__ float4 co_corner_dots(const _Float16* f1p, const _Float16* F2, ptrdiff_t pos11, int C, int W2, int mask,
+                                                 ptrdiff_t pstride, ptrdiff_t cstride) {
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mask & 1) q.x = co_corner_dot(f1p, F2 + pos11 * pstride, C, cstride);
+  if (mask & 2) q.y = co_corner_dot(f1p, F2 + (pos11 + 1) * pstride, C, cstride);
+  if (mask & 4) q.z = co_corner_dot(f1p, F2 + (pos11 + W2) * pstride, C, cstride);
+  if (mask & 8) q.w = co_corner_dot(f1p, F2 + (pos11 + W2 + 1) * pstride, C, cstride);
+  return q;
 }
 
 template <bool IS_MIN>
@@ -131,7 +133,25 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 
 // Compiled for 3 waves per SIMD (168 registers): at 4 (128) the look-ahead of the offsets does not fit and the kernel
 // spills; measured 141 against 107 us for BASELINE config 4.
-constexpr int CO_WPS = 3;
+// Build-time A/B switches (tools/ab_lib_variants.sh), all off in the library:
+//   CO_WPS_N  waves per SIMD the kernel is compiled for (3 = 168 registers).
+//   CO_AFRESH 1 = the fmap1 fragments are loaded at the start of every level's sweep instead of once per wave life, so
+//             that they are not live across the box and sampling phases.
+//   CO_OFRESH 1 = a level's offsets and the coords are not held across its sweep but requested a second time after it.
+// AFRESH + OFRESH bring the kernel to 121 registers with no scratch, i.e. FOUR waves per SIMD (4 workgroups per CU: 151 KB
+// of LDS) — and that build runs BASELINE config 4 in 128-130 us against 111 us for the default on the same box, exactly
+// what the same source compiled for three waves per SIMD takes (129-131 us): the reloads cost 17 % and the fourth wave
+// per SIMD is worth nothing.  The kernel is not bound by occupancy.
+#ifndef CO_WPS_N
+#define CO_WPS_N 3
+#endif
+#ifndef CO_AFRESH
+#define CO_AFRESH 0
+#endif
+#ifndef CO_OFRESH
+#define CO_OFRESH 0
+#endif
+constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
 __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const CoParams p_arg) {
   // The parameter block is read where it lies (the kernarg segment: the only argument, at offset 0), so per-level
@@ -211,32 +231,37 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
   // ---- once per wave life: coords of the own pixels, the first offsets, fmap1 fragments of the whole tile (requested
   // last: loads return in order, and the boxes must not wait for these 8 KB) ----
   float2 cv0[CO_QP];
+#if !CO_AFRESH
   frag a[CO_SB][KS];
+#endif
 #pragma unroll
   for (int q = 0; q < CO_QP; q++)
 #pragma unroll
     for (int i = 0; i < TI; i++) o0[q][i] = make_float2(0.f, 0.f);
-  {
-    CO_FRESH_LANE();
-#pragma unroll
-    for (int q = 0; q < CO_QP; q++) {
-      const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
-      const bool pv = h1 < H1 && w1r < W1;
-      cv0[q] = cbase[pv ? (size_t)h1 * W1 + w1r : 0];
-    }
+#define CO_LOAD_COORDS()                                               \
+  {                                                                    \
+    CO_FRESH_LANE();                                                   \
+    _Pragma("unroll") for (int q = 0; q < CO_QP; q++) {                \
+      const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;                 \
+      const bool pv = h1 < H1 && w1r < W1;                             \
+      cv0[q] = cbase[pv ? (size_t)h1 * W1 + w1r : 0];                  \
+    }                                                                  \
   }
+  CO_LOAD_COORDS()
   request_offsets(lv1 - 1);
-  {
-    CO_FRESH_LANE();
-#pragma unroll
-    for (int m = 0; m < CO_SB; m++) {
-      int h1 = by * 4 + (lx >> 2), w1 = bx * (4 * CO_SB) + m * 4 + (lx & 3);
-      h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;
-      const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;
-#pragma unroll
-      for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s);
-    }
+#define CO_LOAD_A()                                                                         \
+  {                                                                                         \
+    CO_FRESH_LANE();                                                                        \
+    _Pragma("unroll") for (int m = 0; m < CO_SB; m++) {                                     \
+      int h1 = by * 4 + (lx >> 2), w1 = bx * (4 * CO_SB) + m * 4 + (lx & 3);                \
+      h1 = h1 < H1 ? h1 : H1 - 1; w1 = w1 < W1 ? w1 : W1 - 1;                               \
+      const T* ap = F1 + ((size_t)h1 * W1 + w1) * C + EPL * lg;                             \
+      _Pragma("unroll") for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s); \
+    }                                                                                       \
   }
+#if !CO_AFRESH
+  CO_LOAD_A()
+#endif
 
   // (Serving the two zero-offset levels in one box / sweep / sampling pass — their 8-row patches fit one 16-row patch — was
   // built and measured: two barriers less per wave life, but 109 against 105 us; the levels stay one pass each.)
@@ -334,6 +359,10 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       if (lane == 0) { swin[wv * 2] = ulo; swin[wv * 2 + 1] = uhi; }
       CO_STAMP(1);
     }
+#if CO_AFRESH
+    frag a[CO_SB][KS];  // requested before the barrier: they travel while the other waves finish their boxes
+    CO_LOAD_A()
+#endif
     __syncthreads();
 
     // ---- phase 1: the tile window, its rows dealt to the four waves; every fragment meets all four sub-blocks ----
@@ -455,6 +484,10 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       }
       CO_STAMP(3);
     }
+#if CO_OFRESH
+    request_offsets(lvl);  // not held across the sweep: requested again, they travel during the second barrier
+    CO_LOAD_COORDS()
+#endif
     __syncthreads();
 
     // ---- phase 2: sample the patches of the wave's own pixels ----
@@ -477,6 +510,9 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
         // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
         const float* const D0 = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
+#if CO_OFRESH
+        if (!zo && lx == CEN % 16) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap, as phase 0 left it (:80-81)
+#endif
         if (zo) {
           // one sample position per pixel: floor, fraction and the four weights once per pass (products and order are bilerp()'s)
           const float zfx = floorf(cx), zfy = floorf(cy);
