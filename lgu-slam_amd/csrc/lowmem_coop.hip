@@ -439,6 +439,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           // patch entries keep the zeros of phase 0.  A pair straddling the edge (odd W2) stores a zero as its second half.
           unsigned long long colA[CO_SB], colB[CO_SB];
           bool strad1 = false, strad3 = false;  // this lane's position 1 / 3 is the first one right of the map
+          bool strad_any = false;
           int curq = -1;
           for (int it = 0; it < nit; it += PF) {
 #pragma unroll
@@ -462,8 +463,10 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
                   colB[m] = __builtin_amdgcn_ballot_w64((unsigned)(qx + 2) <= (unsigned)swl[m] && xa + 2 < W2);
                 }
                 strad1 = xa + 1 == W2; strad3 = xa + 3 == W2;
+                strad_any = __builtin_amdgcn_ballot_w64(strad1 || strad3) != 0;  // scalar, once per column of groups
               }
-              if (__builtin_amdgcn_ballot_w64(strad1 || strad3) != 0) {  // wave-uniform; only in the last column of groups of an odd-width map
+              if (strad_any) {  // wave-uniform; only in the last column of groups of an odd-width map
+                asm volatile("");  // a real (scalar) branch: if-converted, the eight selects run in every step of every map
 #pragma unroll
                 for (int m = 0; m < CO_SB; m++) {
                   d[m][1] = strad1 ? 0.f : d[m][1];
