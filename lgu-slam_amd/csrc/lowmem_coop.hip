@@ -408,7 +408,11 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           return ((unsigned)lg * GSTR + (unsigned)x * PSTR) * (unsigned)sizeof(T);
         };
         auto load_group = [&](frag (&dstf)[KS], unsigned coff, int y) __attribute__((always_inline)) {
+#ifdef CO_ABL_LOADS   // ablation (timing only, wrong results): every fragment load reads the same aligned 1 KB
+          const unsigned off = (unsigned)(lane0 * 16) + 0u * (coff + (unsigned)y);
+#else
           const unsigned off = coff + (unsigned)y * (YSTR * (unsigned)sizeof(T));  // bytes; the row term is scalar
+#endif
 #pragma unroll
           for (int s = 0; s < KS; s++)
             dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
@@ -450,7 +454,11 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
 #pragma unroll
               for (int s = 0; s < KS; s++)
 #pragma unroll
+#ifdef CO_ABL_MFMA   // ablation (timing only): one cheap VALU op instead of the MFMA
+                for (int m = 0; m < CO_SB; m++) d[m][0] += (float)bq[j][s][0] * (float)a[m][s][0];
+#else
                 for (int m = 0; m < CO_SB; m++) d[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[j][s], a[m][s], d[m], 0, 0, 0);
+#endif
               const int y = ys[j], gq = gqs[j];
               issue(j);
               if (gq != curq) {  // wave-uniform
@@ -478,8 +486,12 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
               for (int m = 0; m < CO_SB; m++) {
                 const unsigned long long rowm = __builtin_amdgcn_ballot_w64((unsigned)(y - sylo[m]) < (unsigned)sbh[m]);
                 float* dst = sbp[m] + yg;
+#ifdef CO_ABL_STORES  // ablation (timing only): a store only where no lane passes
+                if (__builtin_amdgcn_inverse_ballot_w64(rowm & colA[m] & colB[m] & 0ull) || d[m][0] == 12345.678f) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0] + d[m][2], d[m][1] + d[m][3]);
+#else
                 if (__builtin_amdgcn_inverse_ballot_w64(rowm & colA[m])) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0], d[m][1]);
                 if (__builtin_amdgcn_inverse_ballot_w64(rowm & colB[m])) *reinterpret_cast<float2*>(dst + 2) = make_float2(d[m][2], d[m][3]);
+#endif
               }
             }
           }
@@ -509,7 +521,11 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       for (int q = 0; q < CO_QP; q++) {
         const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
         const int4 pb = *reinterpret_cast<const int4*>(pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4);  // row-uniform
+#ifdef CO_ABL_SAMPLE   // ablation (timing only): no patch reads in the sampling phase
+        const bool has_patch = pb.w == 12345, fallback = false;
+#else
         const bool has_patch = pb.w != 0, fallback = pb.z < 0;
+#endif
         // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
         const float* const D0 = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
