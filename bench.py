@@ -348,10 +348,15 @@ def lowmem_roofline(S, dev_ms):
             "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
             "device_ms_per_step": dev_ms,
             "hbm_compulsory_bytes_per_unit": hbm_unit, "hbm_compulsory_GBps": hbm_unit * S["units"] / kern_s / 1e9,
+            "issue": {"instructions_per_launch_B16": 55.8e6 + 4 * 1.96e6, "slot_cycles": 4, "simds": 1024,
+                      "frac_of_issue_rate": ((55.8e6 + 4 * 1.96e6) / 1024 * 4 / 2.4e9) / kern_s if S["B"] == 16 else None,
+                      "source": "profiles/r02_pmc_lowmem_kernels.txt, profiles/r02_lowmem_coop_ablation.txt"},
             "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "
-                    "launch is bound by instruction issue and latency of the per-pixel box / sampling phases around the "
-                    "contraction at 12 waves per CU (DESIGN.md §3.4), not by the MFMA rate: the matrix cores are busy ~12 % "
-                    "of the time (PMC, profiles/)"}
+                    "launch is bound by INSTRUCTION ISSUE of the per-pixel box / sweep-control / sampling / write-out code around "
+                    "the contraction (DESIGN.md §7.2: the instruction counters summed at one instruction per SIMD per 4-cycle slot "
+                    "fill the launch — `issue.frac_of_issue_rate`, from the counters of a 16-edge launch at 2.4 GHz — a build with "
+                    "4 waves per SIMD is no faster, and ablating loads, LDS traffic and MFMAs together removes 16 %), not by the "
+                    "MFMA rate: the matrix cores are busy ~12 % of the time (PMC, profiles/)"}
 
 
 def lowmem_cpu_baseline(S):
