@@ -142,6 +142,9 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 // of LDS) — and that build runs BASELINE config 4 in 128-130 us against 111 us for the default on the same box, exactly
 // what the same source compiled for three waves per SIMD takes (129-131 us): the reloads cost 17 % and the fourth wave
 // per SIMD is worth nothing.  The kernel is not bound by occupancy.
+//   CO_TAILBREAK 1 = an odd trip count of the sweep leaves the loop before its surplus slot (which holds the last group
+//             again) instead of multiplying and storing it a second time: no change (109.9 against 109.2 us).
+//   CO_ABL_LOADS / _STORES / _MFMA / _SAMPLE: timing-only ablations (wrong results), profiles/r02_lowmem_coop_ablation.txt.
 #ifndef CO_WPS_N
 #define CO_WPS_N 3
 #endif
@@ -150,6 +153,9 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 #endif
 #ifndef CO_OFRESH
 #define CO_OFRESH 0
+#endif
+#ifndef CO_TAILBREAK
+#define CO_TAILBREAK 0
 #endif
 constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
@@ -448,6 +454,9 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           for (int it = 0; it < nit; it += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
+#if CO_TAILBREAK
+              if (j > 0 && it + j >= nit) break;  // odd trip count: the surplus slot holds the last group again — leave (scalar branch, no load behind it)
+#endif
               cof32x4 d[CO_SB];
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) d[m] = cof32x4{0.f, 0.f, 0.f, 0.f};
