@@ -352,11 +352,11 @@ def lowmem_roofline(S, dev_ms):
                       "frac_of_issue_rate": ((55.8e6 + 4 * 1.96e6) / 1024 * 4 / 2.4e9) / kern_s if S["B"] == 16 else None,
                       "source": "profiles/r02_pmc_lowmem_kernels.txt, profiles/r02_lowmem_coop_ablation.txt"},
             "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "
-                    "launch is bound by INSTRUCTION ISSUE of the per-pixel box / sweep-control / sampling / write-out code around "
-                    "the contraction (DESIGN.md §7.2: the instruction counters summed at one instruction per SIMD per 4-cycle slot "
-                    "fill the launch — `issue.frac_of_issue_rate`, from the counters of a 16-edge launch at 2.4 GHz — a build with "
-                    "4 waves per SIMD is no faster, and ablating loads, LDS traffic and MFMAs together removes 16 %), not by the "
-                    "MFMA rate: the matrix cores are busy ~12 % of the time (PMC, profiles/)"}
+                    "launch is bound by the per-pixel box / sweep-control / sampling / write-out code around the contraction, "
+                    "not by a data path or the MFMA rate (DESIGN.md §7.2: ablating loads, LDS traffic and MFMAs together removes "
+                    "16 %; a build with 4 waves per SIMD is no faster; the instruction counters summed at one instruction per SIMD "
+                    "per 4-cycle slot would fill the launch — `issue.frac_of_issue_rate`, an over-count, from the counters of a "
+                    "16-edge launch at 2.4 GHz); the matrix cores are busy ~12 % of the time (PMC, profiles/)"}
 
 
 def lowmem_cpu_baseline(S):
