@@ -626,7 +626,13 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
 template <int R, int KS>
 static int launch_coop(CoParams p, hipStream_t st) {
   auto kern = lowmem_coop_kernel<R, KS>;
-  const size_t lds = sizeof(float) * (size_t)CO_LDS_FLOATS;
+  // LGU_LOWMEM_COOP_LDS_PAD (debug / diagnosis only): extra dynamic LDS in KB per workgroup, clamped to the 160 KB of a CU —
+  // fewer resident workgroups per CU, to read a workgroup's life against the number of workgroups sharing the CU
+  size_t lds = sizeof(float) * (size_t)CO_LDS_FLOATS;
+  {
+    const int pad_kb = env_int("LGU_LOWMEM_COOP_LDS_PAD", 0);
+    if (pad_kb > 0) lds = lds + (size_t)pad_kb * 1024 <= 160 * 1024 ? lds + (size_t)pad_kb * 1024 : 160 * 1024;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
