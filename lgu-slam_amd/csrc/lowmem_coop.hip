@@ -144,6 +144,8 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 // per SIMD is worth nothing.  The kernel is not bound by occupancy.
 //   CO_TAILBREAK 1 = an odd trip count of the sweep leaves the loop before its surplus slot (which holds the last group
 //             again) instead of multiplying and storing it a second time: no change (109.9 against 109.2 us).
+//   CO_PRIO   s_setprio around the sweep (1: priority 2, 3: priority 3, 4: + priority 1 in the write-out; 2: the other phases
+//             first): 0 - 2 % on two boxes, within their noise — not adopted.
 //   CO_ABL_LOADS / _STORES / _MFMA / _SAMPLE: timing-only ablations (wrong results), profiles/r02_lowmem_coop_ablation.txt.
 #ifndef CO_WPS_N
 #define CO_WPS_N 3
@@ -156,6 +158,9 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 #endif
 #ifndef CO_TAILBREAK
 #define CO_TAILBREAK 0
+#endif
+#ifndef CO_PRIO
+#define CO_PRIO 0
 #endif
 constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
@@ -424,6 +429,13 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
             dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
         };
         if (nit > 0) {
+#if CO_PRIO == 1 || CO_PRIO == 4
+          __builtin_amdgcn_s_setprio(2);  // A/B: waves in their sweep (loads in flight) issue first
+#elif CO_PRIO == 3
+          __builtin_amdgcn_s_setprio(3);
+#elif CO_PRIO == 2
+          __builtin_amdgcn_s_setprio(0);
+#endif
           // The loop body is branch-free around its loads (a branch around a load makes hipcc wait for nearly every
           // outstanding load at each use): the trip count is rounded up to a multiple of PF and the load cursor stops at
           // the last group, which the surplus steps load and store again.  Slot j remembers which group it holds.
@@ -506,6 +518,11 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           }
         }
       }
+#if CO_PRIO == 1 || CO_PRIO == 3 || CO_PRIO == 4
+      __builtin_amdgcn_s_setprio(0);
+#elif CO_PRIO == 2
+      __builtin_amdgcn_s_setprio(2);  // A/B: the box / sampling / write-out phases issue first
+#endif
       CO_STAMP(3);
     }
 #if CO_OFRESH
@@ -591,6 +608,9 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
 
     // ---- write-out: corr[b][n][ix][iy][h1][w1]; the wave's own patches become its [tap][pixel] transpose tile ----
     {
+#if CO_PRIO == 4
+      __builtin_amdgcn_s_setprio(1);
+#endif
       CO_FRESH_LANE();
       float* const outt = patch + (msb * 16 + qr0 * 4) * CO_PP;  // the patches of the wave's own pixels
 #pragma unroll
@@ -618,6 +638,9 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
         }
       }
       CO_STAMP(5);
+#if CO_PRIO == 4
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
 }
