@@ -1,0 +1,389 @@
+"""The host glue (CorrBlock, AltCorrBlock, GaussianMask, per_Corr_Normalization, offset heads) against the
+REFERENCE'S OWN Python glue.
+
+`tests/golden/glue_*.npz` hold what `/root/reference/droid_slam/modules/corr.py` and `gaussianMask_cuda.py`
+produced when `oracle/gen_glue_golden.py` ran them UNCHANGED in the build container (their three extension
+modules replaced by the CPU oracle's operators, which tests/golden/*.npz pin to the reference kernels):
+seeded inputs, non-zero head weights, raw head outputs, offsets before / after every call, pyramid levels,
+mean_n / theta, every returned tensor, over the life of a block as factor_graph.py drives it (build, look up,
+cat, look up, drop an edge, look up; AltCorrBlock: one block, one call per chunk of edges).
+
+CPU tests: this build's pure-torch compositions (generate_offsets, GaussianMask.gaussian_parameters, both
+per_Corr_Normalization) against the fixtures, and — where /root/reference exists — against the reference's
+functions called directly on fresh inputs; plus a freshness check that the committed fixtures are what the
+generator produces.
+GPU tests (-m gpu): lgu_slam_amd.CorrBlock / AltCorrBlock, every fast path (tiled / row-major pyramid store,
+slot store through cat / __getitem__, fused offsets, lazy / eager AltCorrBlock offsets, call_many, half / float
+frame buffers), on the fixture inputs.
+
+Tolerances (scale = max |reference tensor|):
+  * given the reference's own head outputs / offsets: 1e-5 * scale (north_star's bound);
+  * end to end (own convolutions + own matmul on the GPU against torch-CPU's): offsets 1e-4 absolute (the PCN
+    divides a ~1e-6 convolution difference by the sample's std and 4*tanh stretches it), sampled correlations
+    1e-4 * scale with at most 2e-4 of the entries outside (a tap whose top-left corner sits within ~1e-5 px of
+    the map border flips between 0 and a value — the reference's whole-tap rule).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def T(a, device="cpu"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def build_heads(lgu, h, w, device="cpu"):
+    """ofsMap, ofs_residual, GaussianMask(h, w) of THIS build carrying the fixture's (reference) state dict."""
+    z = gold("glue_heads")
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1)
+    ofs_residual = torch.nn.Conv2d(256, 98, 3, padding=1)
+    GA = lgu.GaussianMask(h, w)
+    for prefix, m in (("w:ofsMap.", ofsMap), ("w:ofs_residual.", ofs_residual), ("w:GA.", GA)):
+        sd = {k[len(prefix):]: T(z[k]) for k in z.files if k.startswith(prefix)}
+        m.load_state_dict(sd, strict=True)
+    for m in (ofsMap, ofs_residual, GA):
+        m.eval().to(device)
+    return ofsMap, ofs_residual, GA
+
+
+def check(got, want, rel=1e-5, what="", outliers=0.0, atol=None):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s != %s" % (what, got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    tol = atol if atol is not None else rel * scale
+    err = np.abs(got - want)
+    frac = float((err > tol).mean())
+    assert frac <= outliers, "%s: max err %.3g (tol %.3g, scale %.3g), %.3g of entries outside (allowed %.3g)" % (
+        what, float(err.max()), tol, scale, frac, outliers)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: fixtures
+def test_per_corr_normalization_both_variants_match_the_reference(lgu):
+    z = gold("glue_functions")
+    check(lgu.corr.per_Corr_Normalization(T(z["pcn4_in"]), [1, 2, 3]), z["pcn4_out"], 1e-6, "corr.py PCN")
+    check(lgu.gaussian_mask.per_Corr_Normalization(T(z["pcn3_in"]), [1, 2]), z["pcn3_out"], 1e-6, "gaussianMask PCN")
+
+
+@pytest.mark.parametrize("name", ["glue_corrblock_16x16", "glue_corrblock_48x64"])
+def test_offset_heads_torch_composition_matches_the_reference_fixture(lgu, name):
+    """generate_offsets / finish_offsets (the composition every fused path falls back to and is tested against)
+    == CorrBlock.fpn_offset_generate of the reference (corr.py:117-135)."""
+    z = gold(name)
+    h, w, Ea = int(z["h"]), int(z["w"]), int(z["E_a"])
+    ys, xs = [int(v) for v in z["pixel_step"]]
+    ofsMap, ofs_residual, _ = build_heads(lgu, h, w)
+    with torch.no_grad():
+        offs, zero = lgu.corr.finish_offsets(T(z["A_raw_o0"]), T(z["A_raw_o1_low"]), 4)
+        assert zero == [False, False, True, True]
+        check(offs[0][:, ::ys, ::xs], z["A_offset0_init"], 1e-6, "level 0 from the reference's head outputs")
+        check(offs[1][:, ::ys, ::xs], z["A_offset1_init"], 1e-6, "level 1 from the reference's head outputs")
+        assert float(offs[2].abs().max()) == 0.0 and tuple(offs[3].shape) == tuple(z["A_offset3_shape"])
+        feats = torch.cat((T(z["fmap1"])[0, :Ea].float(), T(z["fmap2"])[0, :Ea].float()), dim=1)
+        offs, _ = lgu.corr.generate_offsets(ofsMap, ofs_residual, feats, 4)
+        check(offs[0][:, ::ys, ::xs], z["A_offset0_init"], atol=2e-5, what="level 0 end to end (CPU)")
+        check(offs[1][:, ::ys, ::xs], z["A_offset1_init"], atol=2e-5, what="level 1 end to end (CPU)")
+
+
+@pytest.mark.parametrize("name", ["glue_corrblock_16x16", "glue_corrblock_48x64"])
+def test_gaussian_head_torch_composition_matches_the_reference_fixture(lgu, name):
+    """GaussianMask.gaussian_parameters == the reference's GaussianMask.forward up to its kernel call
+    (gaussianMask_cuda.py:66-83): mean = grid + meanMap, cov = 5*sigmoid(PCN(covMap)) + 0.05, det; theta = 2*det."""
+    z = gold(name)
+    h, w, Ea = int(z["h"]), int(z["w"]), int(z["E_a"])
+    _, _, GA = build_heads(lgu, h, w)
+    feats = torch.cat((T(z["fmap1"])[0, :Ea].float(), T(z["fmap2"])[0, :Ea].float()), dim=1)
+    with torch.no_grad():
+        mean, cov, det = GA.gaussian_parameters(feats.permute(0, 2, 3, 1).contiguous())
+    check(mean.view(1, Ea, h, w, 2), z["A_mean_n"], 1e-6, "mean_n")
+    check(2 * det.view(1, Ea, h, w), z["A_theta"], 1e-5, "theta")
+    assert float(cov.min()) >= 0.05 and float(cov.max()) <= 5.05
+    check(cov[..., 0] * cov[..., 1], z["A_theta"][0] / 2, 1e-5, "cov product")
+
+
+# ------------------------------------------------------------------------------------------------ CPU: live reference
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present on this machine")
+
+
+def _gen():
+    sys.dont_write_bytecode = True
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_glue_golden", os.path.join(ROOT, "oracle", "gen_glue_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@needs_ref
+def test_reference_glue_functions_called_directly(lgu):
+    """Fresh inputs through the reference's functions and this build's, side by side (no fixture in between)."""
+    gen = _gen()
+    ref_corr, ref_ga = gen.load_reference_glue()
+    g = torch.Generator().manual_seed(77)
+    h, w, E = 16, 24, 2
+    ofsMap, ofs_residual, ref_GA = gen.make_heads(ref_ga, h, w, seed=9)
+    GA = lgu.GaussianMask(h, w)
+    GA.load_state_dict(ref_GA.state_dict())
+    feats = torch.randn((E, 256, h, w), generator=g) * 0.5
+    with torch.no_grad():
+        holder = type("Holder", (), {})()
+        holder.ofsMap, holder.ofs_residual, holder.offset = ofsMap, ofs_residual, []
+        ref_corr.CorrBlock.fpn_offset_generate(holder, feats)
+        offs, zero = lgu.corr.generate_offsets(ofsMap, ofs_residual, feats, 4)
+        for l in range(4):
+            assert torch.equal(offs[l].contiguous(), holder.offset[l].contiguous()) or \
+                float((offs[l] - holder.offset[l]).abs().max()) <= 2e-6, "level %d" % l
+        holder.offset = []
+        ref_corr.AltCorrBlock.offset_generate(holder, feats)
+        for l in range(4):
+            assert float((offs[l] - holder.offset[l]).abs().max()) <= 2e-6
+        # Gaussian head: the reference's forward with the kernel call replaced by the oracle (stand-in module)
+        vol = torch.randn((E, h, w, h, w), generator=g)
+        x = feats.permute(0, 2, 3, 1).contiguous()
+        ref_v, ref_mean, ref_det = ref_GA(x, vol)
+        mean, cov, det = GA.gaussian_parameters(x)
+        assert float((mean - ref_mean).abs().max()) <= 1e-5 and float((det - ref_det).abs().max()) <= 1e-5
+        from oracle import oracle as O
+        v1, = O.gaussianMask(mean.numpy(), cov.numpy(), vol.numpy(), 4)
+        mine = torch.from_numpy(v1) / (6.28 * torch.sqrt(det).view(E, h, w, 1, 1)) + vol
+        assert float((mine - ref_v).abs().max()) <= 1e-5 * float(ref_v.abs().max())
+
+
+@needs_ref
+def test_committed_glue_fixtures_are_what_the_generator_produces():
+    gen = _gen()
+    fresh = gen.corrblock_scenario(16, 16, 2, 1, seed=101)
+    z = gold("glue_corrblock_16x16")
+    assert set(fresh) == set(z.files)
+    for k in z.files:
+        a, b = np.asarray(fresh[k]), z[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype.kind == "f":
+            assert np.abs(a.astype(np.float64) - b).max() <= 2e-5 * max(1.0, float(np.abs(b).max())), k
+        else:
+            assert np.array_equal(a, b), k
+    heads = gen.heads_state(*gen.make_heads(gen.load_reference_glue()[1], 16, 16))
+    zh = gold("glue_heads")
+    assert set(heads) == set(zh.files) and all(np.array_equal(heads[k], zh[k]) for k in zh.files)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _require_gpu(lgu):
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert os.path.exists(lgu._lib.so_path()), "liblgu_corr.so missing — run __graft_entry__.build()"
+    lgu._lib.load()
+
+
+def _px(t, z):
+    ys, xs = [int(v) for v in z["pixel_step"]]
+    return t[:, ::ys, ::xs]
+
+
+def _rowmajor_levels(lgu, blk):
+    lv = blk.corr_pyramid
+    if blk._tiled:
+        lv = [lgu.ops.volume_retile(v.contiguous(), to_tiled=False, hw=blk._level_hw[i]) for i, v in enumerate(lv)]
+    return lv
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inject", ["reference_offsets", "end_to_end"])
+@pytest.mark.parametrize("tiled", [True, False])
+@pytest.mark.parametrize("name", ["glue_corrblock_16x16", "glue_corrblock_48x64"])
+def test_corrblock_life_against_the_reference_glue(lgu, name, tiled, inject, monkeypatch):
+    """CorrBlock build -> call -> cat -> call -> __getitem__ -> call, exactly the reference's scenario.
+    inject = reference_offsets: the block's offsets are overwritten with the reference's initial ones, so the
+    lookups (probe, compounding mask, centre zeroing, slot store, cat / drop bookkeeping) are held to 1e-5 * scale;
+    end_to_end: nothing injected, the stated end-to-end bounds."""
+    _require_gpu(lgu)
+    monkeypatch.setattr(lgu.CorrBlock, "TILED_PYRAMID", tiled)
+    z = gold(name)
+    h, w, Ea, Eb = int(z["h"]), int(z["w"]), int(z["E_a"]), int(z["E_b"])
+    ys, xs = [int(v) for v in z["pixel_step"]]
+    E = Ea + Eb
+    d = "cuda"
+    ofsMap, ofs_residual, GA = build_heads(lgu, h, w, d)
+    f1, f2 = T(z["fmap1"], d).float(), T(z["fmap2"], d).float()
+    exact = inject == "reference_offsets"
+    if exact and (ys, xs) != (1, 1):
+        pytest.skip("the production-shape fixture stores offsets on a pixel sub-grid: nothing to inject")
+    rel_out, frac_out = (1e-5, 2e-5) if exact else (1e-4, 2e-4)
+    full = (ys, xs) == (1, 1)
+    with torch.no_grad():
+        A = lgu.CorrBlock(ofsMap, ofs_residual, GA, f1[:, :Ea], f2[:, :Ea], num_levels=4, radius=3)
+        assert A._store is not None and A._tiled == tiled, "the fused builder / slot store must be what runs here"
+        check(A.mean_n, z["A_mean_n"], 2e-6, "mean_n")
+        check(A.theta, z["A_theta"], 1e-5, "theta")
+        for l, lv in enumerate(_rowmajor_levels(lgu, A)):
+            got = lv if full else lv[:, ::ys * 4, ::xs * 4]
+            check(got, z["A_pyr%d" % l], 1e-5, "pyramid level %d" % l)
+        check(_px(A.offset[0], z), z["A_offset0_init"], atol=1e-4, what="offset 0 (own convolution)")
+        check(_px(A.offset[1], z), z["A_offset1_init"], atol=1e-4, what="offset 1 (own convolution)")
+        assert float(A.offset[2].abs().max()) == 0.0 and tuple(A.offset[3].shape) == tuple(z["A_offset3_shape"])
+        if exact:
+            A.offset[0] = T(z["A_offset0_init"], d).clone()
+            A.offset[1] = T(z["A_offset1_init"], d).clone()
+        r1, mean_n, theta = A(T(z["coords1"], d)[:, :Ea])
+        assert mean_n is A.mean_n and theta is A.theta and r1.shape == (1, Ea, 196, h, w) and r1.is_contiguous()
+        check(r1[:, :, :, ::ys, ::xs], z["out1"], rel_out, "first lookup", frac_out)
+        tol = dict(rel=1e-5) if exact else dict(atol=1e-4)
+        check(_px(A.offset[0], z), z["A_offset0_after1"], what="offset 0 after call 1 (centre zeroed)", **tol)
+        check(_px(A.offset[1], z), z["A_offset1_after1"], what="offset 1 after call 1 (masked)", **tol)
+        assert float(A.offset[0].view(Ea, h, w, 7, 7, 2)[:, :, :, 3, 3].abs().max()) == 0.0
+
+        B = lgu.CorrBlock(ofsMap, ofs_residual, GA, f1[:, Ea:], f2[:, Ea:], num_levels=4, radius=3)
+        check(B.mean_n, z["B_mean_n"], 2e-6, "B mean_n")
+        check(B.theta, z["B_theta"], 1e-5, "B theta")
+        if exact:
+            B.offset[0] = T(z["B_offset0_init"], d).clone()
+            B.offset[1] = T(z["B_offset1_init"], d).clone()
+        else:
+            check(_px(B.offset[0], z), z["B_offset0_init"], atol=1e-4, what="B offset 0")
+            check(_px(B.offset[1], z), z["B_offset1_init"], atol=1e-4, what="B offset 1")
+        A = A.cat(B)
+        assert A._store is not None and tuple(A.corr_pyramid[1].shape[:3]) == tuple(z["AB_pyr1_shape"][:3])
+        r2, _, _ = A(T(z["coords2"], d))
+        check(r2[:, :, :, ::ys, ::xs], z["out2"], rel_out, "lookup after cat", frac_out)
+        check(_px(A.offset[0], z), z["AB_offset0_after2"], what="offset 0 after call 2", **tol)
+        check(_px(A.offset[1], z), z["AB_offset1_after2"], what="offset 1 after call 2 (mask compounded)", **tol)
+
+        keep = T(z["keep"], d)
+        A = A[keep]
+        r3, _, _ = A(T(z["coords3"], d)[:, keep])
+        assert r3.shape == (1, E - 1, 196, h, w)
+        check(r3[:, :, :, ::ys, ::xs], z["out3"], rel_out, "lookup after dropping an edge", frac_out)
+        check(_px(A.offset[1], z), z["AB_offset1_after3"], what="offset 1 after call 3", **tol)
+        assert A.offset[2].shape[0] == E - 1 and float(A.offset[2].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["glue_corrblock_16x16"])
+def test_corrblock_reference_composition_path_against_the_reference_glue(lgu, name, monkeypatch):
+    """The same life through the NON-fused paths (what training and unsupported shapes take): torch composition of the
+    offsets and the Gaussian head, GaussianMaskCuda + avg_pool2d pyramid, per-level autograd samplers."""
+    _require_gpu(lgu)
+    monkeypatch.setattr(lgu.corr, "FUSED_OFFSETS", False)
+    monkeypatch.setattr(lgu.gaussian_mask, "FUSED_PARAMS", False)
+    z = gold(name)
+    h, w, Ea = int(z["h"]), int(z["w"]), int(z["E_a"])
+    d = "cuda"
+    ofsMap, ofs_residual, GA = build_heads(lgu, h, w, d)
+    for q in list(ofsMap.parameters()) + list(ofs_residual.parameters()):
+        q.requires_grad_(True)     # trainable offset heads: CorrBlock takes the reference-shaped autograd composition
+    f1, f2 = T(z["fmap1"], d).float(), T(z["fmap2"], d).float()
+    A = lgu.CorrBlock(ofsMap, ofs_residual, GA, f1[:, :Ea], f2[:, :Ea], num_levels=4, radius=3)
+    assert A._store is None and A.offset[0].requires_grad
+    for l, lv in enumerate(A.corr_pyramid):
+        check(lv, z["A_pyr%d" % l], 1e-5, "pyramid level %d" % l)
+    check(A.offset[0], z["A_offset0_init"], atol=1e-4, what="offset 0")
+    check(A.offset[1], z["A_offset1_init"], atol=1e-4, what="offset 1")
+    r1, _, _ = A(T(z["coords1"], d)[:, :Ea])
+    assert r1.grad_fn is not None
+    check(r1, z["out1"], 1e-4, "first lookup (autograd composition)", 2e-4)
+    check(A.offset[1], z["A_offset1_after1"], atol=1e-4, what="offset 1 after call 1")
+
+
+def _alt_block(lgu, z, h, w, half, d):
+    ofsMap, ofs_residual, GA = build_heads(lgu, h, w, d)
+    fm = T(z["fmaps"], d)
+    blk = lgu.AltCorrBlock(ofsMap, ofs_residual, GA, fm if half else fm.float(), num_levels=4, radius=3)
+    return blk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lazy", [True, False])
+@pytest.mark.parametrize("half", [True, False])
+@pytest.mark.parametrize("name", ["glue_altcorr_16x16", "glue_altcorr_24x32"])
+def test_altcorrblock_calls_against_the_reference_glue(lgu, name, half, lazy, monkeypatch):
+    """AltCorrBlock(frame buffer)(coords, ii, jj) per chunk of edges == the reference's, for a half buffer (what
+    depth_video holds; matrix-core path) and a float one, with the first-edge-only offsets of the fast path on and off.
+    `offset` afterwards == the reference's attribute (every edge's rows; only edge 0's centre taps zeroed)."""
+    _require_gpu(lgu)
+    monkeypatch.setattr(lgu.AltCorrBlock, "LAZY_OFFSETS", lazy)
+    z = gold(name)
+    tag = "h" if half else "f"
+    if "%s_c0_out" % tag not in z.files:
+        pytest.skip("this fixture holds the half-buffer run only")
+    h, w = int(z["h"]), int(z["w"])
+    d = "cuda"
+    with torch.no_grad():
+        blk = _alt_block(lgu, z, h, w, half, d)
+        for l in range(1, 4):
+            assert blk.pyramid[l].dtype == (torch.float16 if half else torch.float32)
+            check(blk.pyramid[l], z["%s_pyr%d" % (tag, l)].astype(np.float32), 1e-3 if half else 1e-6, "frame pyramid %d" % l)
+        for c in range(int(z["n_calls"])):
+            ii, jj = T(z["c%d_ii" % c], d), T(z["c%d_jj" % c], d)
+            r = blk(T(z["c%d_coords" % c], d), ii, jj)
+            want = z["%s_c%d_out" % (tag, c)]
+            assert tuple(r.shape) == want.shape and r.is_contiguous()
+            check(r, want, 1e-4, "call %d" % c, 2e-4)
+            o0, o1 = blk.offset[0], blk.offset[1]
+            check(o0.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset0_after" % (tag, c)], atol=1e-4, what="offset 0 of call %d" % c)
+            check(o1.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset1_after" % (tag, c)], atol=1e-4, what="offset 1 of call %d" % c)
+            assert float(blk.offset[2].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_altcorrblock_call_many_against_the_reference_glue(lgu):
+    """The chunk loop of update_lowmem in ONE launch (call_many) == the reference's calls, chunk by chunk."""
+    _require_gpu(lgu)
+    z = gold("glue_altcorr_16x16")
+    h, w, d = int(z["h"]), int(z["w"]), "cuda"
+    n = int(z["n_calls"])
+    with torch.no_grad():
+        blk = _alt_block(lgu, z, h, w, True, d)
+        ii = torch.cat([T(z["c%d_ii" % c], d) for c in range(n)])
+        jj = torch.cat([T(z["c%d_jj" % c], d) for c in range(n)])
+        co = torch.cat([T(z["c%d_coords" % c], d) for c in range(n)], dim=1)
+        counts = [int(z["c%d_ii" % c].shape[0]) for c in range(n)]
+        r = blk.call_many(co, ii, jj, counts)
+        assert getattr(blk, "one_launch_calls", 0) == 1, "the one-launch path must be what ran"
+        want = np.concatenate([z["h_c%d_out" % c] for c in range(n)], axis=1)
+        check(r, want, 1e-4, "call_many", 2e-4)
+        last = n - 1
+        check(blk.offset[1].reshape(counts[last], h, w, 98), z["h_c%d_offset1_after" % last], atol=1e-4,
+              what="offset 1 after call_many == the last call's")
+
+
+@pytest.mark.gpu
+def test_altcorrblock_given_the_reference_head_outputs(lgu):
+    """Offsets formed from the REFERENCE's raw head outputs by this build's fused post-processing (PCN, tanh, mix,
+    nearest up-sampling, probe mask) and sampled by the fused lookup: 1e-5 * scale against the reference's call."""
+    _require_gpu(lgu)
+    z = gold("glue_altcorr_16x16")
+    h, w, d = int(z["h"]), int(z["w"]), "cuda"
+    with torch.no_grad():
+        blk = _alt_block(lgu, z, h, w, True, d)
+        frames = blk._frame_operands()
+        for c in range(int(z["n_calls"])):
+            ii, jj = T(z["c%d_ii" % c], d), T(z["c%d_jj" % c], d)
+            E = ii.shape[0]
+            c0 = T(z["c%d_coords" % c], d).reshape(E, 1, h, w, 2).contiguous()
+            probe = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], [blk._chunked[1]], c0, [None], 1, ii=ii, jj=jj, lbase=1,
+                                                         chunked=True)
+            offs, zero = lgu.corr.finish_offsets(T(z["h_c%d_raw_o0" % c], d), T(z["h_c%d_raw_o1_low" % c], d), 4, probe=probe)
+            assert zero == [False, False, True, True]
+            # before the sampler zeroes edge 0's centre taps: compare everything but those
+            w0 = z["h_c%d_offset0_after" % c].reshape(E, h, w, 7, 7, 2).copy()
+            g0 = offs[0].reshape(E, h, w, 7, 7, 2).clone()
+            g0[0, :, :, 3, 3] = 0
+            check(g0, w0, 1e-5, "offset 0 from the reference's head outputs")
+            w1 = z["h_c%d_offset1_after" % c].reshape(E, h, w, 7, 7, 2)
+            g1 = offs[1].reshape(E, h, w, 7, 7, 2).clone()
+            g1[0, :, :, 3, 3] = 0
+            check(g1, w1, 1e-5, "offset 1 (masked) from the reference's head outputs")
+            rows = [o.contiguous().view(E, h, w, 7, 7, 2).float() if not zz else None for o, zz in zip(offs, zero)]
+            out = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], blk._chunked, c0, rows, 3, ii=ii, jj=jj, chunked=True)
+            check(out.view(1, E, 196, h, w), z["h_c%d_out" % c], 1e-5, "lookup given the reference's offsets", 2e-5)
