@@ -58,9 +58,18 @@ def build_heads(lgu, h, w, device="cpu"):
     return ofsMap, ofs_residual, GA
 
 
-def check(got, want, rel=1e-5, what="", outliers=0.0, atol=None):
+def check(got, want, rel=1e-5, what="", outliers=0.0, atol=None, centre=True):
+    """centre=False: offsets (..., 98 = 7*7*2) compared with the centre tap's pair zeroed on both sides.  No operator
+    reads that pair (every sampler overwrites it with 0 first, defCorrSample_kernel.cu:51-52), and what the reference's
+    ATTRIBUTE holds there is an accident of tensor contiguity: `self.offset[i].contiguous()` (corr.py:102) is a copy for
+    the freshly permuted tensors, so the zeroing lands in a temporary, but a no-op after `cat` / `offset[1] * mask`, so
+    there it lands in the attribute.  This build's blocks keep contiguous offsets and always hold the zero."""
     got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = np.asarray(want)
+    if not centre:
+        got, want = got.reshape(got.shape[:-1] + (7, 7, 2)).copy(), want.reshape(want.shape[:-1] + (7, 7, 2)).copy()
+        got[..., 3, 3, :] = 0
+        want[..., 3, 3, :] = 0
     assert got.shape == want.shape, "%s: shape %s != %s" % (what, got.shape, want.shape)
     scale = max(float(np.abs(want).max()), 1e-30)
     tol = atol if atol is not None else rel * scale
@@ -239,8 +248,8 @@ def test_corrblock_life_against_the_reference_glue(lgu, name, tiled, inject, mon
         assert mean_n is A.mean_n and theta is A.theta and r1.shape == (1, Ea, 196, h, w) and r1.is_contiguous()
         check(r1[:, :, :, ::ys, ::xs], z["out1"], rel_out, "first lookup", frac_out)
         tol = dict(rel=1e-5) if exact else dict(atol=1e-4)
-        check(_px(A.offset[0], z), z["A_offset0_after1"], what="offset 0 after call 1 (centre zeroed)", **tol)
-        check(_px(A.offset[1], z), z["A_offset1_after1"], what="offset 1 after call 1 (masked)", **tol)
+        check(_px(A.offset[0], z), z["A_offset0_after1"], what="offset 0 after call 1", centre=False, **tol)
+        check(_px(A.offset[1], z), z["A_offset1_after1"], what="offset 1 after call 1 (masked)", centre=False, **tol)
         assert float(A.offset[0].view(Ea, h, w, 7, 7, 2)[:, :, :, 3, 3].abs().max()) == 0.0
 
         B = lgu.CorrBlock(ofsMap, ofs_residual, GA, f1[:, Ea:], f2[:, Ea:], num_levels=4, radius=3)
@@ -253,18 +262,21 @@ def test_corrblock_life_against_the_reference_glue(lgu, name, tiled, inject, mon
             check(_px(B.offset[0], z), z["B_offset0_init"], atol=1e-4, what="B offset 0")
             check(_px(B.offset[1], z), z["B_offset1_init"], atol=1e-4, what="B offset 1")
         A = A.cat(B)
-        assert A._store is not None and tuple(A.corr_pyramid[1].shape[:3]) == tuple(z["AB_pyr1_shape"][:3])
+        # (row-major 16x16: level 3 is 2 wide, which the fused row-major lookup does not serve — the block has left the
+        # slot store for the per-operator path by now; every other case is still slot-indirected)
+        assert (A._store is not None) == (tiled or w >= 32)
+        assert tuple(A.corr_pyramid[1].shape[:3]) == tuple(z["AB_pyr1_shape"][:3])
         r2, _, _ = A(T(z["coords2"], d))
         check(r2[:, :, :, ::ys, ::xs], z["out2"], rel_out, "lookup after cat", frac_out)
-        check(_px(A.offset[0], z), z["AB_offset0_after2"], what="offset 0 after call 2", **tol)
-        check(_px(A.offset[1], z), z["AB_offset1_after2"], what="offset 1 after call 2 (mask compounded)", **tol)
+        check(_px(A.offset[0], z), z["AB_offset0_after2"], what="offset 0 after call 2", centre=False, **tol)
+        check(_px(A.offset[1], z), z["AB_offset1_after2"], what="offset 1 after call 2 (mask compounded)", centre=False, **tol)
 
         keep = T(z["keep"], d)
         A = A[keep]
         r3, _, _ = A(T(z["coords3"], d)[:, keep])
         assert r3.shape == (1, E - 1, 196, h, w)
         check(r3[:, :, :, ::ys, ::xs], z["out3"], rel_out, "lookup after dropping an edge", frac_out)
-        check(_px(A.offset[1], z), z["AB_offset1_after3"], what="offset 1 after call 3", **tol)
+        check(_px(A.offset[1], z), z["AB_offset1_after3"], what="offset 1 after call 3", centre=False, **tol)
         assert A.offset[2].shape[0] == E - 1 and float(A.offset[2].abs().max()) == 0.0
 
 
@@ -292,7 +304,7 @@ def test_corrblock_reference_composition_path_against_the_reference_glue(lgu, na
     r1, _, _ = A(T(z["coords1"], d)[:, :Ea])
     assert r1.grad_fn is not None
     check(r1, z["out1"], 1e-4, "first lookup (autograd composition)", 2e-4)
-    check(A.offset[1], z["A_offset1_after1"], atol=1e-4, what="offset 1 after call 1")
+    check(A.offset[1], z["A_offset1_after1"], atol=1e-4, what="offset 1 after call 1", centre=False)
 
 
 def _alt_block(lgu, z, h, w, half, d):
@@ -330,8 +342,8 @@ def test_altcorrblock_calls_against_the_reference_glue(lgu, name, half, lazy, mo
             assert tuple(r.shape) == want.shape and r.is_contiguous()
             check(r, want, 1e-4, "call %d" % c, 2e-4)
             o0, o1 = blk.offset[0], blk.offset[1]
-            check(o0.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset0_after" % (tag, c)], atol=1e-4, what="offset 0 of call %d" % c)
-            check(o1.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset1_after" % (tag, c)], atol=1e-4, what="offset 1 of call %d" % c)
+            check(o0.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset0_after" % (tag, c)], atol=1e-4, what="offset 0 of call %d" % c, centre=False)
+            check(o1.reshape(want.shape[1], h, w, 98), z["%s_c%d_offset1_after" % (tag, c)], atol=1e-4, what="offset 1 of call %d" % c, centre=False)
             assert float(blk.offset[2].abs().max()) == 0.0
 
 
@@ -354,7 +366,7 @@ def test_altcorrblock_call_many_against_the_reference_glue(lgu):
         check(r, want, 1e-4, "call_many", 2e-4)
         last = n - 1
         check(blk.offset[1].reshape(counts[last], h, w, 98), z["h_c%d_offset1_after" % last], atol=1e-4,
-              what="offset 1 after call_many == the last call's")
+              what="offset 1 after call_many == the last call's", centre=False)
 
 
 @pytest.mark.gpu
@@ -375,15 +387,8 @@ def test_altcorrblock_given_the_reference_head_outputs(lgu):
                                                          chunked=True)
             offs, zero = lgu.corr.finish_offsets(T(z["h_c%d_raw_o0" % c], d), T(z["h_c%d_raw_o1_low" % c], d), 4, probe=probe)
             assert zero == [False, False, True, True]
-            # before the sampler zeroes edge 0's centre taps: compare everything but those
-            w0 = z["h_c%d_offset0_after" % c].reshape(E, h, w, 7, 7, 2).copy()
-            g0 = offs[0].reshape(E, h, w, 7, 7, 2).clone()
-            g0[0, :, :, 3, 3] = 0
-            check(g0, w0, 1e-5, "offset 0 from the reference's head outputs")
-            w1 = z["h_c%d_offset1_after" % c].reshape(E, h, w, 7, 7, 2)
-            g1 = offs[1].reshape(E, h, w, 7, 7, 2).clone()
-            g1[0, :, :, 3, 3] = 0
-            check(g1, w1, 1e-5, "offset 1 (masked) from the reference's head outputs")
+            check(offs[0], z["h_c%d_offset0_after" % c], 1e-5, "offset 0 from the reference's head outputs", centre=False)
+            check(offs[1], z["h_c%d_offset1_after" % c], 1e-5, "offset 1 (masked) from the reference's head outputs", centre=False)
             rows = [o.contiguous().view(E, h, w, 7, 7, 2).float() if not zz else None for o, zz in zip(offs, zero)]
             out = lgu.ops.lowmem_pyramid_forward_mixed(frames[0], blk._chunked, c0, rows, 3, ii=ii, jj=jj, chunked=True)
             check(out.view(1, E, 196, h, w), z["h_c%d_out" % c], 1e-5, "lookup given the reference's offsets", 2e-5)
