@@ -17,11 +17,17 @@ is.  `extra.warm_cache` holds the replay figure next to it.
 BASELINE config 3 (E=40) and config 4 (lowmem) — each the median of --blocks blocks of
 --steps launches, device time by HIP events on the launch stream.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): factor-graph edges are
-independent, so every rank samples its own E edges (weak scaling, no data-path
-collective); `value` = all ranks' units / max-over-ranks time.  The sharded driver's one
-real exchange — the all-gather of per-edge target/weight before BA
-(factor_graph.py:290-300) — is timed separately and reported under "exchange".
+Multi-GPU (--gpus N): one process per GPU over RCCL.  Under torch.distributed.run the ranks
+are the launcher's; from a plain `python bench.py --gpus N` this process — before it touches
+any GPU — starts the N ranks itself (torch.distributed.run as a child process), relays rank
+0's one JSON line and exits non-zero if any rank failed.  `n_gpus` is the number of ranks the
+process group actually initialised.  Factor-graph edges are independent, so for the headline
+every rank samples its own E edges (weak scaling, no data-path collective); `value` = all
+ranks' units / max-over-ranks time.  The multi-GPU DESIGN — BASELINE config 5: one global-BA
+iteration over a fixed ~2000-edge graph, source-frame chunks dealt to the ranks, all-gathers
+of target / weight / damping, replicated BA: STRONG scaling — is measured in the same run
+and reported under "strong_scaling_config5" (N > 1) / extra.config5_backend_n1 (N = 1).
+The per-BA-step all-gather alone is also timed ("exchange").
 
 Prints ONE JSON line on rank 0.
 """
@@ -148,6 +154,7 @@ def dry_run_cpu(args, rank, world):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend="gloo")
+    n_ranks = dist.get_world_size() if world > 1 else 1
     E, H1, W1 = args.edges, 48, 64
 
     def barrier():
@@ -171,18 +178,67 @@ def dry_run_cpu(args, rank, world):
         allv = torch.empty(world * E, H1, W1, 4)
         dist.all_gather_into_tensor(allv, mine)
         exchange = {"op": "all_gather(target,weight) over gloo (dry run)", "bytes_per_rank": mine.numel() * 4, "ms": 0.0}
+    strong = None
+    if not args.no_backend:
+        # the config-5 leg's control flow: fixed edge list, source-frame chunks dealt to the ranks, exchanged, agreement checked
+        import lgu_slam_amd
+        sh = lgu_slam_amd.sharded
+        ii = torch.arange(64).repeat_interleave(2)
+        edges = sh.ShardedEdgeSet(ii, rank=rank, world=world)
+        target = torch.zeros(ii.numel(), 2)
+        local = torch.full((edges.counts[rank], 2), float(rank + 1))
+        edges.gather(local, out=target)
+        agree = sh.replicas_agree(target) if world > 1 else True
+        strong = {"workload": "DRY RUN of the config-5 control flow (no kernel executed)", "n_gpus": n_ranks,
+                  "edges_total": int(ii.numel()), "edges_per_rank": edges.counts, "replicas_agree": agree,
+                  "every_edge_owned": bool((target != 0).all())}
     if rank == 0:
-        res = {"metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)", "value": world * E * H1 * W1 / (wall / args.steps) / 1e6,
-               "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        res = {"metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)", "value": n_ranks * E * H1 * W1 / (wall / args.steps) / 1e6,
+               "unit": "Mpix·edges/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic", "config": {"workload": "DRY RUN (no kernel executed)"},
                "roofline": None, "cpu_baseline": None}
         if exchange:
             res["exchange"] = exchange
+        if strong is not None:
+            res["strong_scaling_config5" if n_ranks > 1 else "config5_backend_n1"] = strong
         emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside any launcher: start the N ranks as CHILD processes, one per GPU,
+    through torch.distributed.run on 127.0.0.1 with a free port; relay rank 0's JSON line; exit with the launcher's
+    status.  This parent makes no GPU / HIP call before or after (a process that has touched the GPU must not be
+    replaced or forked into ranks), and nothing is re-exec'd."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)   # stderr passes through
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(proc.stdout.decode(errors="replace"))
+        sys.stderr.write("bench: the %d-rank launch failed (launcher exit code %d)\n" % (args.gpus, proc.returncode))
+        sys.exit(proc.returncode or 1)
+    try:
+        got = json.loads(lines[-1]).get("n_gpus")
+    except ValueError:
+        got = None
+    if got != args.gpus:
+        sys.stderr.write("bench: asked for %d ranks, the line reports n_gpus = %r\n" % (args.gpus, got))
+        sys.exit(1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    sys.exit(0)
 
 
 _REAL_STDOUT = None
@@ -348,15 +404,13 @@ def lowmem_roofline(S, dev_ms):
             "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
             "device_ms_per_step": dev_ms,
             "hbm_compulsory_bytes_per_unit": hbm_unit, "hbm_compulsory_GBps": hbm_unit * S["units"] / kern_s / 1e9,
-            "issue": {"instructions_per_launch_B16": 55.8e6 + 4 * 1.96e6, "slot_cycles": 4, "simds": 1024,
-                      "frac_of_issue_rate": ((55.8e6 + 4 * 1.96e6) / 1024 * 4 / 2.4e9) / kern_s if S["B"] == 16 else None,
-                      "source": "profiles/r02_pmc_lowmem_kernels.txt, profiles/r02_lowmem_coop_ablation.txt"},
             "note": "on-the-fly correlation is a contraction over C=128 followed by a 49-tap bilinear sample per level; the "
                     "launch is bound by the per-pixel box / sweep-control / sampling / write-out code around the contraction, "
                     "not by a data path or the MFMA rate (DESIGN.md §7.2: ablating loads, LDS traffic and MFMAs together removes "
-                    "16 %; a build with 4 waves per SIMD is no faster; the instruction counters summed at one instruction per SIMD "
-                    "per 4-cycle slot would fill the launch — `issue.frac_of_issue_rate`, an over-count, from the counters of a "
-                    "16-edge launch at 2.4 GHz); the matrix cores are busy ~12 % of the time (PMC, profiles/)"}
+                    "16 %; a build with 4 waves per SIMD is no faster; one profile's instruction counters — ~56 M VALU/SALU/LDS/VMEM + "
+                    "2 M MFMA wave-instructions per 16-edge launch, profiles/r02_pmc_lowmem_kernels.txt — summed at one instruction per "
+                    "SIMD per 4-cycle slot would roughly fill the launch; that sum over-counts (dual issue) and is a reading aid, not a "
+                    "measured fraction); the matrix cores are busy ~12 % of the time (PMC, profiles/)"}
 
 
 def lowmem_cpu_baseline(S):
@@ -384,6 +438,10 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
     per-level loop of AltCorrBlock.corr_fn (corr.py:192-213) = ONE fused launch (lgu_lowmem_pyramid_fwd_h16)."""
     S = lowmem_setup(ops, dev, args.edges, 4321 + rank)
     plan, coords, out, units = S["plan"], S["coords"], S["out"], S["units"]
+    n_ranks = 1
+    if use_dist:
+        import torch.distributed as dist
+        n_ranks = dist.get_world_size()
 
     def barrier():
         if use_dist:
@@ -417,7 +475,7 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
         roof = lowmem_roofline(S, float(np.median(blocks)))
         roof["device_ms_per_step_blocks"] = blocks
         res = {"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4)",
-               "value": world * units / (wall / args.steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps,
+               "value": n_ranks * units / (wall / args.steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": n_ranks, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f16 features, f32 accumulate", "data": "synthetic",
                "config": {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, one chunk of "
@@ -434,6 +492,17 @@ def lowmem_main(args, ops, dev, rank, world, use_dist):
 
 
 def backend_main(args, lgu, dev, rank, world, use_dist):
+    """--workload backend: the config-5 step as the whole run's line."""
+    res = backend_run(args, lgu, dev, rank, world, use_dist, args.steps, args.warmup)
+    if rank == 0:
+        emit(res)
+    if use_dist:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
     """BASELINE config 5: one global-BA iteration of update_lowmem (reference factor_graph.py:256-302) over a ~2000-edge
     factor graph (200 keyframes of 60x80x128 half feature maps, edges between frames at most 5 apart = 1970 edges),
     STRONG scaling: the graph is fixed and its source-frame chunks are dealt round-robin to the ranks.  One step =
@@ -442,9 +511,11 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                 weight = sigmoid of the next ones, damping = per-source-frame mean)
       exchange  all-gather of target / weight by edge and of damping by source frame (RCCL)
       ba        dense bundle adjustment, 2 iterations, replicated on every rank (parity unpinned, experimental)
-    `value` = pixel·edges of the WHOLE graph per second of step time (max over ranks)."""
+    `value` = pixel·edges of the WHOLE graph per second of step time (max over ranks).
+    Every rank calls this (it issues collectives); returns the record on rank 0, None elsewhere."""
     import torch.distributed as dist
     sh = lgu.sharded
+    n_ranks = dist.get_world_size() if use_dist else 1
     N, H, W, C, span = 200, 60, 80, 128, 5
     g = torch.Generator(device=dev)
     g.manual_seed(777)  # the same graph and state on every rank (replicated, as the SLAM system holds them)
@@ -553,7 +624,7 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(False)
     it_no[0] = 0   # the timed region starts with a call's first iteration
     import gc
@@ -562,10 +633,11 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
                    # objects of ~2000 tensors per step in --chunk-loop mode) no longer rescan them inside the timed region
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(True)
     barrier()
     wall = time.perf_counter() - t0
+    gc.unfreeze()
     agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and world > 1 else True
     if use_dist:
         t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))],
@@ -576,9 +648,9 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
         ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))]
     if rank == 0:
         units = E * H * W
-        emit({"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4; global BA step)",
-              "value": units / (wall / args.steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps,
-              "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+        return {"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4; global BA step)",
+              "value": units / (wall / steps) / 1e6, "unit": "Mpix·edges/s", "n_gpus": n_ranks, "steps": steps,
+              "warmup": warmup, "ms_per_step": wall * 1e3 / steps, "higher_is_better": True, "scaling": "strong",
               "vs_baseline": None, "dtype": "f16 features, f32 accumulate; f32/f64 BA", "data": "synthetic",
               "config": {"workload": "BASELINE config 5: one update_lowmem iteration over a %d-edge graph (%d keyframes, 60x80x128 half "
                                      "features), source-frame chunks of 8 dealt round-robin to %d rank(s); lookups + all-gathers + "
@@ -601,10 +673,8 @@ def backend_main(args, lgu, dev, rank, world, use_dist):
               "step_wall_ms_this_rank": [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + step_wall[:-1], step_wall)],
               "ms_per_step_median_this_rank": float(np.median([(b_ - a_) * 1e3 for a_, b_ in zip([t0] + step_wall[:-1], step_wall)])),
               "replicas_agree": agree,
-              "roofline": None, "cpu_baseline": None})
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+              "roofline": None, "cpu_baseline": None}
+    return None
 
 
 def kernel_name(variant, probe, tiled, out_format):
@@ -673,6 +743,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the timed steps one by one from Python instead of replaying "
                                                              "them from one HIP graph")
     ap.add_argument("--randn-volumes", action="store_true", help="N(0,1) volumes instead of fmap products")
+    ap.add_argument("--no-backend", action="store_true", help="skip the BASELINE config-5 leg (one sharded global-BA iteration, strong "
+                    "scaling) that the default workload reports beside the headline")
+    ap.add_argument("--backend-steps", type=int, default=8, help="timed steps of the config-5 leg inside the default workload")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: exercise the launch / process-group / timing / JSON logic with gloo on CPU and an "
                          "empty step (no kernel runs, the printed value is meaningless)")
@@ -680,11 +753,15 @@ def main():
     global NO_GRAPH
     NO_GRAPH = args.no_graph
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])   # no launcher around us: be the launcher (never returns)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if args.dry_run_cpu:
         return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
@@ -698,7 +775,10 @@ def main():
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)  # RCCL
-    if args.variant:
+        if dist.get_world_size() != world:
+            raise SystemExit("RCCL initialised %d ranks, the launcher promised %d" % (dist.get_world_size(), world))
+    if args.variant:   # A/B only: the library honours its debug variables only when asked to at load time
+        os.environ["LGU_DEBUG_KNOBS"] = "1"
         os.environ["LGU_DEFCORR_VARIANT"] = str(args.variant)
 
     import lgu_slam_amd
@@ -757,8 +837,12 @@ def main():
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    n_ranks = 1
+    if use_dist:
+        import torch.distributed as dist
+        n_ranks = dist.get_world_size()   # the ranks RCCL actually initialised
     ms_per_step = wall * 1e3 / args.steps
-    value = world * units / (wall / args.steps) / 1e6
+    value = n_ranks * units / (wall / args.steps) / 1e6
 
     exchange = None
     if use_dist:  # the sharded driver's per-BA-step all-gather of target+weight (E,ht,wd,2)x2
@@ -778,6 +862,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exchange = {"op": "all_gather(target,weight) over RCCL", "bytes_per_rank": mine.numel() * 4,
                     "ms": float(t.item()) * 1e3}
+
+    # BASELINE config 5 in the same run: the multi-GPU design proper (fixed graph, chunks dealt to the ranks, all-gathers,
+    # BA) — STRONG scaling; every rank takes part (collectives)
+    strong = None
+    if not args.no_backend:
+        strong = backend_run(args, lgu_slam_amd, dev, rank, world, use_dist, args.backend_steps, 3)
+        torch.cuda.empty_cache()
 
     if rank == 0:
         A, U = algorithmic_bytes_per_unit(sets.rowmajor[0], sets.coords[0], sets.offs[0], R)
@@ -799,7 +890,7 @@ def main():
                      "warm: every launch re-reads the same inputs (touched set ~243 MiB can stay in the Infinity Cache)"
         res = {
             "metric": "def-corr-sample Mpix·edges/s (48×64 fmap, r=3, L=4)",
-            "value": value, "unit": "Mpix·edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Mpix·edges/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: TartanAir-mono shape, 48x64 fmap, L=4, r=3, "
@@ -824,8 +915,23 @@ def main():
                          "device_ms_per_step_timed_region": dev_ms / args.steps},
             "cpu_baseline": None,
         }
+        res["config"]["library"] = lgu_slam_amd._lib.version()
         if want_extra:
             res["extra"] = extras(args, ops, dev, sets, A_planar, kern_ms)
+            res["extra"].update(glue_extras(lgu_slam_amd, dev, args))
+        if strong is not None:
+            keep = {k: strong[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype",
+                                           "phases_ms_max_over_ranks", "ms_per_step_median_this_rank", "replicas_agree")}
+            keep["workload"] = strong["config"]["workload"]
+            keep["edges_total"], keep["edges_this_rank"] = strong["config"]["edges_total"], strong["config"]["edges_this_rank"]
+            keep["ba"] = strong["config"]["ba"]
+            keep["note"] = ("strong scaling: the graph is fixed, `value` = its pixel·edges per second of step time (max over ranks); "
+                            "lookups shrink with the rank count, exchange and the replicated BA do not (DESIGN.md §6); "
+                            "`python bench.py --workload backend --gpus N [--ba-split]` runs this leg alone with more steps")
+            if n_ranks > 1:
+                res["strong_scaling_config5"] = keep
+            else:
+                res.setdefault("extra", {})["config5_backend_n1"] = keep
         if not (args.no_cpu or world > 1):  # rank 0, N=1 only
             res["cpu_baseline"] = cpu_baseline(E, H1, W1, L, R)
         if exchange:
@@ -886,13 +992,109 @@ def extras(args, ops, dev, sets, A, headline_ms):
     del s40, p40, p40p
     torch.cuda.empty_cache()
     # (d) BASELINE config 4: lowmem
-    S = lowmem_setup(ops, dev, 16, 4321)
-    lb = time_blocks(lambda i: S["plan"](S["coords"], out=S["out"]), steps, blocks)
-    lm = float(np.median(lb))
-    ex["config4_lowmem"] = {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, 16 edges, all "
-                                        "levels in one launch", "device_ms_per_step": lm, "Mpix_edges_per_s": S["units"] / lm / 1e3,
-                            "blocks_ms": [round(x, 5) for x in lb], "roofline": lowmem_roofline(S, lm)}
+    # 16 edges = 2 400 workgroups over 1 024 slots = 2.3 rounds (tail quantisation); 64 edges is a backend chunk's size
+    # (B ~ 50-150) — both stated
+    for B, key in ((16, "config4_lowmem"), (64, "config4_lowmem_B64")):
+        S = lowmem_setup(ops, dev, B, 4321)
+        lb = time_blocks(lambda i: S["plan"](S["coords"], out=S["out"]), steps, blocks)
+        lm = float(np.median(lb))
+        ex[key] = {"workload": "BASELINE config 4: lowMem_defSample, 60x80x128 half feature maps, L=4, r=3, %d edges, all "
+                               "levels in one launch" % B, "device_ms_per_step": lm, "Mpix_edges_per_s": S["units"] / lm / 1e3,
+                   "device_us_per_edge": lm * 1e3 / B, "blocks_ms": [round(x, 5) for x in lb], "roofline": lowmem_roofline(S, lm)}
+        del S
+        torch.cuda.empty_cache()
     return ex
+
+
+def glue_extras(lgu, dev, args):
+    """Host-glue costs in the driver-run line: CorrBlock.__init__ at E = 20 (fp32 maps, and half maps
+    under autocast as factor_graph.py:90 builds it) with the HBM fraction of its volume post-processing, and
+    AltCorrBlock.__call__ on a 16-edge chunk at 60x80.  Device time by HIP events around whole calls (Python included:
+    these are multi-launch host paths)."""
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    E, h, w = 20, 48, 64
+    with torch.no_grad():
+        ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+        ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+        GA = lgu.GaussianMask(h, w).to(dev)
+        f1 = torch.randn(1, E, 128, h, w, device=dev, generator=g) * 0.5
+        f2 = torch.randn(1, E, 128, h, w, device=dev, generator=g) * 0.5
+        units = E * h * w
+        # SURVEY §8(d), a5 + f1: per pixel·edge the post-processing must read the raw slice once and write the level-0 slice
+        # (12 288 B each at 48x64) and the three pooled levels (+ 32.8 %), plus 16 B of Gaussian parameters: what ONE fused
+        # pass moves.  (a5 alone — read 16 + 81*4 B, write 12 288 B — is SURVEY's 12.6 KB/unit.)
+        a5_bytes = 16 + 81 * 4 + h * w * 4
+        f1_bytes = 16 + h * w * 4 + int(h * w * 4 * (1 + 1 / 4 + 1 / 16 + 1 / 64))
+        for half in (False, True):
+            a, b = (f1.half(), f2.half()) if half else (f1, f2)
+            times = []
+            for it in range(14):
+                e0, e1 = _events()
+                e0.record()
+                with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                    blk = lgu.CorrBlock(ofsMap, ofsRes, GA, a, b)
+                e1.record()
+                e1.synchronize()
+                if it >= 4:
+                    times.append(e0.elapsed_time(e1))
+            # the fused volume post-processing launch alone (gaussianMask + /denominator + corr + 3 poolings: a5 + f1)
+            mean_n, cov, det = GA.gaussian_parameters(blk.t)
+            raw = lgu.CorrBlock.corr(a, b).view(E, h, w, h, w)
+            raw = raw.contiguous() if half else raw.float().contiguous()
+            vp = []
+            for it in range(12):
+                src = raw.clone()
+                e0, e1 = _events()
+                e0.record()
+                lgu.ops.volume_pyramid(mean_n.float().contiguous(), cov.float().contiguous(), src, 4, 4, inplace=True, tiled=True,
+                                       det=det.contiguous())
+                e1.record()
+                e1.synchronize()
+                if it >= 2:
+                    vp.append(e0.elapsed_time(e1))
+            ms, vms = float(np.median(times)), float(np.median(vp))
+            in_bytes = h * w * (2 if half else 4)
+            fused_bytes = 16 + in_bytes + int(h * w * 4 * (1 + 1 / 4 + 1 / 16 + 1 / 64))
+            out["corrblock_init_E20_%s" % ("half_autocast" if half else "fp32")] = {
+                "workload": "CorrBlock.__init__, 20 edges of 48x64x128 %s maps: all-pairs matmul, two offset heads + post-processing, "
+                            "Gaussian head, fused volume post-processing into the 4-level tiled pyramid" % ("half (autocast)" if half else "fp32"),
+                "device_ms_per_construction": ms, "us_per_edge": ms * 1e3 / E,
+                "volume_postprocessing_kernel": {
+                    "device_ms": vms, "algorithmic_bytes_per_unit_fused": fused_bytes,
+                    "hbm_GBps": fused_bytes * units / (vms * 1e-3) / 1e9, "hbm_frac": fused_bytes * units / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "a5_alone_bytes_per_unit_SURVEY": a5_bytes,
+                    "note": "one pass: reads the raw slice (%d B) + 16 B parameters, writes levels 0-3 (fp32, +32.8 %%); a5 alone by "
+                            "SURVEY §8(d) is 12.6 KB/unit (write-dominated) — the fused pass moves %.1f KB/unit and replaces the reference's "
+                            "memset + mask + 2 elementwise + 3 pooling passes" % (in_bytes, fused_bytes / 1024.0)}}
+            del blk, raw, src
+        del f1, f2, a, b
+        torch.cuda.empty_cache()
+        # AltCorrBlock.__call__: 16 edges over 8 frames at 60x80 (half buffer, as depth_video holds it)
+        N, H, W = 8, 60, 80
+        fm = (torch.randn(1, N, 128, H, W, device=dev, generator=g) * 0.5).half()
+        ofsMap2 = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+        ofsRes2 = torch.nn.Conv2d(256, 98, 3, padding=1).to(dev)
+        ii = torch.arange(16, device=dev) // 2
+        jj = (ii + 1 + torch.arange(16, device=dev) % 2) % N
+        ys, xs = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing="ij")
+        coords = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, 16, H, W, 2, device=dev, generator=g)).contiguous()
+        blk = lgu.AltCorrBlock(ofsMap2, ofsRes2, None, fm)
+        times = []
+        for it in range(24):
+            e0, e1 = _events()
+            e0.record()
+            blk(coords, ii, jj)
+            e1.record()
+            e1.synchronize()
+            if it >= 4:
+                times.append(e0.elapsed_time(e1))
+        ms = float(np.median(times))
+        out["altcorrblock_call"] = {"workload": "AltCorrBlock.__call__, 16 edges over 8 frames of 60x80x128 half maps: level-1 probe, offset heads "
+                                                "of the call's first edge + post-processing, fused 4-level low-memory lookup",
+                                    "device_ms_per_call": ms, "Mpix_edges_per_s": 16 * H * W / ms / 1e3}
+    return out
 
 
 if __name__ == "__main__":

@@ -15,7 +15,10 @@
  *   - the return value is 0 on success, a hipError_t value if the launch failed, or
  *     one of the LGU_E_* codes below for arguments the kernels cannot serve;
  *     nothing throws; lgu_error_string() names any code;
- *   - re-entrant, no mutable global state;
+ *   - re-entrant; no mutable global state beyond idempotent per-device launch caches ("this kernel may use > 64 KB of
+ *     LDS on device d", the device's CU count: the same values whoever writes them) and one flag read when the library
+ *     is loaded: the LGU_* debug environment variables that select superseded kernels for tests / A-B tools are
+ *     honoured only if LGU_DEBUG_KNOBS=1 was set at load time — otherwise no entry point reads the environment;
  *   - "fully written" outputs need no initialisation by the caller; "accumulated"
  *     outputs must be zero-filled by the caller before the call (the reference
  *     allocates them with torch::zeros / zeros_like).
@@ -37,8 +40,11 @@ extern "C" {
 #define LGU_MAX_LEVELS 8
 #define LGU_MAX_RADIUS 7
 
-/* Library identification: "lgu_corr <semver> gfx950". */
+/* Library identification: "lgu_corr <semver> gfx950", followed by " [<extra compiler flags>]" for a non-default
+ * (experiment) build. */
 const char* lgu_version(void);
+/* 1 if the library was loaded with LGU_DEBUG_KNOBS=1 in the environment (debug / A-B knobs live), else 0. */
+int lgu_debug_knobs_enabled(void);
 /* Static string for a code returned by any entry point (LGU_E_* or hipError_t). */
 const char* lgu_error_string(int code);
 

@@ -14,7 +14,7 @@ from .corr import AltCorrBlock, CorrBlock, CorrSampler, DefCorrSampler, per_Corr
 from .encoder import CorrEncoder  # noqa: F401
 from .gaussian_mask import GaussianMask, GaussianMaskCuda  # noqa: F401
 
-__version__ = "0.6.0"
+__version__ = "0.7.0"
 
 DROPIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin")
 

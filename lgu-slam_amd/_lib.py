@@ -87,7 +87,9 @@ LGU_E_BADARG, LGU_E_UNSUPPORTED = 100001, 100002
 
 
 def so_path():
-    return _build.SO_PATH
+    """The library this process loads.  LGU_LIB_PATH (experiments only: tools/ab_lib_*.sh) points at another build —
+    variants are loaded from where they were built, the in-tree default library is never overwritten."""
+    return os.environ.get("LGU_LIB_PATH") or _build.SO_PATH
 
 
 def load():
@@ -113,6 +115,8 @@ def load():
     lib.lgu_offsets_finalize_scratch_bytes.restype = ctypes.c_longlong
     lib.lgu_offsets_finalize_scratch_bytes.argtypes = [_int]
     lib.lgu_version.restype = ctypes.c_char_p
+    lib.lgu_debug_knobs_enabled.restype = _int
+    lib.lgu_debug_knobs_enabled.argtypes = []
     lib.lgu_error_string.restype = ctypes.c_char_p
     lib.lgu_error_string.argtypes = [_int]
     _lib = lib
@@ -127,3 +131,8 @@ def check(code, what):
 
 def version():
     return load().lgu_version().decode()
+
+
+def debug_knobs_enabled():
+    """True if the LGU_* debug variables are live in this process (LGU_DEBUG_KNOBS=1 when the library was loaded)."""
+    return bool(load().lgu_debug_knobs_enabled())

@@ -63,7 +63,29 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
 
 
 HEAD_CACHE = os.environ.get("LGU_HEAD_CACHE", "1") != "0"   # debug / A-B only: 0 = one convolution per edge and call
+HEAD_CACHE_MAX_BYTES = 1 << 30   # the per-frame partial convolutions (4.7 MB per 48 x 64 frame for both heads) are kept only
+                                 # while they fit this budget for the WHOLE frame buffer the block was given (update_lowmem
+                                 # hands over video.fmaps: 512 frames would be 2.4 GB); beyond it the heads are convolved per
+                                 # edge (ops.offset_conv_frames), which needs no per-frame state
 FUSED_OFFSETS = True   # False: the reference-shaped torch composition below also in inference (A/B and tests)
+
+
+class _Snapshot:
+    """Identity of the tensors a cached derivative was made from: the tensor OBJECTS themselves (held, so their ids
+    cannot be recycled), their version counters (in-place writes, load_state_dict) and their storage addresses
+    (`.data = ...` swaps).  A fresh Parameter that happens to land in a freed allocator block with version 0 — the same
+    (data_ptr, _version) pair as the one it replaces — is a different object and does not match."""
+
+    __slots__ = ("tensors", "marks")
+
+    def __init__(self, tensors):
+        self.tensors = tuple(tensors)
+        self.marks = tuple((t._version, t.data_ptr()) for t in self.tensors)
+
+    def matches(self, tensors):
+        tensors = tuple(tensors)
+        return (len(tensors) == len(self.tensors) and all(a is b for a, b in zip(tensors, self.tensors))
+                and self.marks == tuple((t._version, t.data_ptr()) for t in tensors))
 
 
 def _zero_offsets(like, n):
@@ -428,8 +450,10 @@ class AltCorrBlock:
         frames = [p_[0].contiguous() for p_ in self.pyramid]
         if self.pyramid[0].dtype != torch.float16:
             frames = [f.float() for f in frames]
-        if getattr(self, "_chunked", None) is None or self._chunked[0].dtype != frames[0].dtype:
+        if (getattr(self, "_chunked", None) is None or self._chunked[0].dtype != frames[0].dtype
+                or not self._chunked_snap.matches(self.pyramid)):    # rewritten / replaced levels: re-derive
             self._chunked = [ops.lowmem_chunked(f) for f in frames]
+            self._chunked_snap = _Snapshot(self.pyramid)
         return frames
 
     def call_many(self, coords, ii, jj, counts):
@@ -477,7 +501,7 @@ class AltCorrBlock:
                 return ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], cs, [None], 1, ii=i_, jj=j_, lbase=1,
                                                         chunked=True)
 
-            firsts = self._offsets_from_frames(1, i0, j0, probe=probe_of(c0[first], i0, j0), store=False)
+            firsts = self._offsets_from_frames(1, i0, j0, probe=probe_of(c0[first], i0, j0), store=False, per_frame=False)
             if firsts is False:
                 return one_by_one()
             rows, zero_level = firsts
@@ -495,13 +519,16 @@ class AltCorrBlock:
         out = fused.view(1, E, -1, H, W)
         return out if squeeze else out.unsqueeze(-1)
 
-    def _offsets_from_frames(self, B, ii, jj, probe=None, store=True):
+    def _offsets_from_frames(self, B, ii, jj, probe=None, store=True, per_frame=True):
         """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
         run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
         (E,256,H,W) tensor, fp32-accurate split-half weights).  The residual head's input, the 2 x 2 average of the
         frames, is pooled ONCE per block instead of per call (the same fp32 averages of the same numbers: pooling
         commutes with the per-edge gather) and split into two half parts.  The rest is finish_offsets.  Sets
-        self.offset; returns False when the general composition has to run."""
+        self.offset; returns False when the general composition has to run.
+        per_frame=False: convolve per edge, without the per-frame partial-convolution cache — what the first-edge-only
+        calls ask for (one edge per chunk: its two frames are not met again within the block's life, so the cache would
+        hold 2 x 98 x H x W floats per frame of the buffer for nothing)."""
         conv = self.ofsMap
         C = self.pyramid[0].shape[-1]
         if not (FUSED_OFFSETS and B == 1 and self.num_levels >= 2 and self.pyramid[0].dtype == torch.float16
@@ -517,16 +544,18 @@ class AltCorrBlock:
                     and res.out_channels <= 112 and res.kernel_size == (3, 3) and res.padding == (1, 1)
                     and res.stride == (1, 1) and res.dilation == (1, 1) and res.groups == 1
                     and res.weight.dtype == torch.float32)
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version,
-               tuple((q.data_ptr(), q._version) for q in res.parameters()))
-        if getattr(self, "_ofs_key", None) != key:
+        heads = [conv.weight, conv.bias] + list(res.parameters())
+        if getattr(self, "_ofs_snap", None) is None or not self._ofs_snap.matches(heads):
             self._ofs_packed = ops.pack_offset_conv(conv.weight, conv.bias)
             self._res_packed = ops.pack_offset_conv(res.weight, res.bias) if res_fast else None
-            self._ofs_key = key
-        frames0 = self.pyramid[0][0]
-        pkey = (frames0.data_ptr(), frames0._version, res_fast)
-        if getattr(self, "_pooled", None) is None or getattr(self, "_pooled_key", None) != pkey:
-            self._pooled_key = pkey
+            self._ofs_snap = _Snapshot(heads)
+            self._head_snap = None       # the per-frame partial convolutions were made with the old weights
+        level0 = self.pyramid[0]
+        frames0 = level0[0]
+        if (getattr(self, "_pooled", None) is None or not self._pooled_snap.matches([level0])
+                or self._pooled_fast != res_fast):
+            self._pooled_snap, self._pooled_fast = _Snapshot([level0]), res_fast
+            self._head_snap = None       # ... or from the old frames
             # 2 x 2 averages of the frames in fp32, as avg_pool2d of the reference's fp32 input gives them (x 4 is a power
             # of two and moves to the weights exactly), channel-last, split into two half parts: hi + lo == the average
             # to 2^-22.  The general path keeps the fp32 averages (x 4) in NCHW.
@@ -539,16 +568,17 @@ class AltCorrBlock:
                 self._pooled = (pooled * 4.0,)
         iic, jjc = ii.contiguous(), jj.contiguous()
         try:
-            if HEAD_CACHE and res_fast and C % 64 == 0:
+            nf, hh, ww = frames0.shape[0], frames0.shape[1], frames0.shape[2]
+            cache_bytes = 2 * 4 * nf * conv.out_channels * (hh * ww + (hh // 2) * (ww // 2))
+            if HEAD_CACHE and per_frame and res_fast and C % 64 == 0 and cache_bytes <= HEAD_CACHE_MAX_BYTES:
                 # per-frame partial convolutions, kept for the life of this block (ops.OffsetHeadCache): the heads are
                 # linear in cat(frame ii, frame jj), a frame is source / target of ~10 edges each and the block serves
                 # every chunk of an update_lowmem pass, so each frame is convolved once and an edge costs a sum
-                hkey = (key, frames0.data_ptr(), frames0._version)   # new weights or a rewritten pyramid: the partials are stale
-                if getattr(self, "_head_key", None) != hkey:
+                if getattr(self, "_head_snap", None) is None:   # new weights or a rewritten pyramid: the partials are stale
                     self._head0 = ops.OffsetHeadCache(frames0, ops.pack_offset_conv_parts(conv.weight, conv.bias))
                     self._head1 = ops.OffsetHeadCache(self._pooled[0], ops.pack_offset_conv_parts(res.weight, res.bias),
                                                       frames_lo=self._pooled[1])
-                    self._head_key = hkey
+                    self._head_snap = True
                 E = iic.shape[0]
                 work = self._head0.mark(iic, jjc)   # one claim pass for both heads: they need the same frames
                 self._head0.convolve(work, E)
@@ -631,7 +661,7 @@ class AltCorrBlock:
             # Only the first edge's offsets are ever read (class docstring): probe, heads, post-processing for that edge.
             try:
                 i0, j0 = iic[:1], jjc[:1]
-                first = self._offsets_from_frames(B, i0, j0, probe=run_probe(1), store=False)
+                first = self._offsets_from_frames(B, i0, j0, probe=run_probe(1), store=False, per_frame=False)
                 if first is not False:
                     rows, zero_level = first
                     offs = [None if zero_level[i] else rows[i].contiguous().view(1, H, W, rd, rd, 2).float()

@@ -623,11 +623,7 @@ int lgu_ba_solve_f64(const double* A, const double* b, float* x, int P, double l
   const int n = 6 * P;
   if (n > BA_SOLVE_MAXN) return LGU_E_UNSUPPORTED;  // larger systems: the caller uses a library factorisation
   const size_t lds = sizeof(double) * ((((size_t)n * (n + 1)) >> 1) + n + 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_max_dynamic_lds<&ba_solve_kernel>();
   hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds, reinterpret_cast<hipStream_t>(stream), A, b, x, n, lm, ep);
   return launch_status();
 }

@@ -317,11 +317,7 @@ int lgu_ba_solve_blocked_f64(double* A, const double* b, float* x, double* work,
   double* ext = work;
   int* flag = reinterpret_cast<int*>(work + n);
   double* stage = work + n + 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_max_dynamic_lds<&chol_backsolve_kernel>();
   hipLaunchKernelGGL(chol_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, b, ext, flag, n, lm, ep);
   for (int k0 = 0; k0 < n; k0 += CH_NB) {
     const int w = n - k0 < CH_NB ? n - k0 : CH_NB;

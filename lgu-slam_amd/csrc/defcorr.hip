@@ -860,27 +860,24 @@ static int launch_fast(const PyrParams& p, hipStream_t st) {
   constexpr int tpx = KIND >= 11 ? 16 : KIND >= 9 ? 8 : (KIND == 3 || KIND >= 5) ? 32 : TP;
   const size_t lds = KIND == 0 ? pyr_lds_bytes(p.L, R) : KIND == 8 ? (size_t)ENC_LDS_BYTES
                      : (KIND == 9 || KIND == 10) ? 0 : sizeof(float) * ((size_t)p.L * nt_ * (tpx + 1)) + lds_pad();  // pad: occupancy experiments (tools/ab_cold.py)
-  // if constexpr: only the kernel of this KIND is instantiated
-  void (*kern)(const PyrParams);
-  if constexpr (KIND == 0) kern = defcorr_pyr_kernel<R, PROBE, ZMASK>;
-  else if constexpr (KIND == 1) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 4, 16, false>;
-  else if constexpr (KIND == 2) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false>;
-  else if constexpr (KIND == 3) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, false>;
-  else if constexpr (KIND == 4) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
-  else if constexpr (KIND == 5) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
-  else if constexpr (KIND == 8) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
-  else if constexpr (KIND == 9) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 2>;
-  else if constexpr (KIND == 10) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 1>;
-  else if constexpr (KIND == 11) kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true, 0, true>;
-  else kern = defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false, 0, true>;
+  // only the kernel of this KIND is instantiated
+  constexpr auto kern = [] {
+    if constexpr (KIND == 0) return &defcorr_pyr_kernel<R, PROBE, ZMASK>;
+    else if constexpr (KIND == 1) return &defcorr_gather_kernel<R, PROBE, ZMASK, 4, 16, false>;
+    else if constexpr (KIND == 2) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false>;
+    else if constexpr (KIND == 3) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, false>;
+    else if constexpr (KIND == 4) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true>;
+    else if constexpr (KIND == 5) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true>;
+    else if constexpr (KIND == 8) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 32, true, 3>;
+    else if constexpr (KIND == 9) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 2>;
+    else if constexpr (KIND == 10) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 8, true, 1>;
+    else if constexpr (KIND == 11) return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, true, 0, true>;
+    else return &defcorr_gather_kernel<R, PROBE, ZMASK, 2, 16, false, 0, true>;
+  }();
   const int nthreads = KIND >= 11 ? 8 * kWave : KIND >= 9 ? (tpx / 2) * kWave : (KIND == 3 || KIND >= 5) ? 16 * kWave : (KIND == 2 || KIND == 4) ? 8 * kWave : NWAVE * kWave;
   PyrParams q = p;
   q.tiles_per_row = (p.W1 + tpx - 1) / tpx;
-  static bool attr_set = false;  // idempotent; racing setters write the same value
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_max_dynamic_lds<kern>();
   const unsigned grid = (unsigned)((size_t)q.E * q.H1 * q.tiles_per_row);
   if (KIND == 2 || KIND == 4 || KIND >= 11) q.flags |= PYR_INT_XCD_REMAP;  // 16-pixel tiles with planar output
   hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, st, q);

@@ -160,18 +160,19 @@ __global__ __launch_bounds__(NWV* kWave, 6) void defcorr_lean_kernel(
 
   const float* const vb[NL] = {v0, v1, v2, v3};
 
-  // ---- probe lattice (level 1, 4 x 4 around coords / 2 on lanes 0..15), issued first: level 1 waits for it ----
-  float platv[GP];
+  // ---- probe lattices (level 1, 4 x 4 around coords / 2): pixel 0 on lanes 0..15, pixel 1 on lanes 16..31 — one
+  // register and one load for both pixels, issued first: level 1 waits for it ----
+  float platv = 0.0f;
+  const bool pr1 = (lane & 16u) != 0u;                    // row 0 / row 1 of the wave = this wave's first / second pixel
+  float psx = 0.0f, psy = 0.0f;
   if constexpr (PROBE) {
-#pragma unroll
-    for (int k = 0; k < GP; k++) {
-      const float sx = cx[k] * 0.5f, sy = cy[k] * 0.5f;
-      const int X = (int)floorf(sx) - 1 + (int)(lane & 3u), Y = (int)floorf(sy) - 1 + (int)((lane >> 2) & 3u);
-      const float* sl = vb[1] + (size_t)(vrow_pix + (k ? pxb : pxa)) * (unsigned)g.ssz[1];
-      platv[k] = 0.0f;
-      if (lane < 16 && (unsigned)X < (unsigned)g.W2[1] && (unsigned)Y < (unsigned)g.H2[1])
-        platv[k] = ldg<float>(sl, (pos_y<TILED>(Y, g.W2[1], g.tpr[1]) + pos_x<TILED>(X)) * 4u);
-    }
+    psx = (pr1 ? cx[1] : cx[0]) * 0.5f;
+    psy = (pr1 ? cy[1] : cy[0]) * 0.5f;
+    const int X = (int)floorf(psx) - 1 + (int)(lane & 3u), Y = (int)floorf(psy) - 1 + (int)((lane >> 2) & 3u);
+    const float* sl = vb[1] + (size_t)(vrow_pix + pxa) * (unsigned)g.ssz[1];
+    const unsigned dsl = pr1 ? (pxb - pxa) * (unsigned)g.ssz[1] * 4u : 0u;   // the second pixel's slice: 0 or one slice on
+    if (lane < 32 && (unsigned)X < (unsigned)g.W2[1] && (unsigned)Y < (unsigned)g.H2[1])
+      platv = ldg<float>(sl, (pos_y<TILED>(Y, g.W2[1], g.tpr[1]) + pos_x<TILED>(X)) * 4u + dsl);
   }
 
   // ---- phase A: issue every load before any result is used ----
@@ -256,28 +257,30 @@ __global__ __launch_bounds__(NWV* kWave, 6) void defcorr_lean_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
 
-  // ---- probe -> mask -> level-1 offsets (corr.py:94-99), then the level-1 gathers ----
+  // ---- probe -> mask -> level-1 offsets (corr.py:94-99), then the level-1 gathers.  Both pixels' 3 x 3 probes are
+  // blended and reduced at once, one per row of 16 lanes (the row sums below are row-relative). ----
   if constexpr (PROBE) {
+    const int H2 = g.H2[1], W2 = g.W2[1];
+    const unsigned l16 = lane & 15u;
+    const int pi = (int)l16 / 3, pj = (int)l16 - pi * 3;
+    const int src = (int)(lane & 16u) + ((pj * 4 + pi) & 15);
+    const float q11 = __shfl(platv, src, kWave), q21 = __shfl(platv, src + 1, kWave);
+    const float q12 = __shfl(platv, src + 4, kWave), q22 = __shfl(platv, src + 5, kWave);
+    const float fxs = floorf(psx), fys = floorf(psy);
+    const float dx = psx - fxs, dy = psy - fys;
+    const int x1 = (int)fxs - 1 + pi, y1 = (int)fys - 1 + pj;
+    float v = 0.0f;
+    if (l16 < 9 && in_bounds(y1, x1, H2, W2)) v = bilerp(q11, q21, q12, q22, dx, dy);
+    const float mean = row16_sum(v) / 9.0f;
+    const float dd = l16 < 9 ? v - mean : 0.0f;
+    const float var = row16_sum(dd * dd) / 8.0f;  // unbiased, torch.var default
+    const float m = 1.0f / (1.0f + expf(-var));
+    const float mk[GP] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0)),
+                          __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16))};
 #pragma unroll
     for (int k = 0; k < GP; k++) {
-      const int H2 = g.H2[1], W2 = g.W2[1];
-      const float sx = cx[k] * 0.5f, sy = cy[k] * 0.5f;
-      const int pi = (int)lane / 3, pj = (int)lane - pi * 3;
-      const int src = (pj * 4 + pi) & 15;
-      const float q11 = __shfl(platv[k], src, kWave), q21 = __shfl(platv[k], src + 1, kWave);
-      const float q12 = __shfl(platv[k], src + 4, kWave), q22 = __shfl(platv[k], (src + 5) & 15, kWave);
-      const float fxs = floorf(sx), fys = floorf(sy);
-      const float dx = sx - fxs, dy = sy - fys;
-      const int x1 = (int)fxs - 1 + pi, y1 = (int)fys - 1 + pj;
-      float v = 0.0f;
-      if (lane < 9 && in_bounds(y1, x1, H2, W2)) v = bilerp(q11, q21, q12, q22, dx, dy);
-      const float mean = row16_sum(lane < 9 ? v : 0.0f) / 9.0f;
-      const float dd = lane < 9 ? v - mean : 0.0f;
-      const float var = row16_sum(dd * dd) / 8.0f;  // unbiased, torch.var default
-      const float m = 1.0f / (1.0f + expf(-var));
-      const float mk = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
-      of[k][1].x *= mk;
-      of[k][1].y *= mk;
+      of[k][1].x *= mk[k];
+      of[k][1].y *= mk[k];
       // persistent offset[1] *= mask (corr.py:99); the centre stays 0
       if (tap && !centre && pv[k])
         reinterpret_cast<f32x2a*>(off1 + (size_t)(row_pix + (k ? pxb : pxa)) * (NT * 2))[lane] = of[k][1];

@@ -354,11 +354,8 @@ static int volume_pyramid_host(const float* means, const float* covs, const void
   p.npix = (size_t)E * H1 * W1; p.H2 = H2; p.W2 = W2; p.L = L; p.r = radius;
   auto kern = half_in ? (tiled ? volume_pyramid_kernel<true, true> : volume_pyramid_kernel<false, true>)
                       : (tiled ? volume_pyramid_kernel<true, false> : volume_pyramid_kernel<false, false>);
-  static bool attr_set[4] = {false, false, false, false};
-  if (!attr_set[tiled + 2 * half_in]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[tiled + 2 * half_in] = true;
-  }
+  if (half_in) { if (tiled) allow_max_dynamic_lds<&volume_pyramid_kernel<true, true>>(); else allow_max_dynamic_lds<&volume_pyramid_kernel<false, true>>(); }
+  else { if (tiled) allow_max_dynamic_lds<&volume_pyramid_kernel<true, false>>(); else allow_max_dynamic_lds<&volume_pyramid_kernel<false, false>>(); }
   hipLaunchKernelGGL(kern, dim3((unsigned)p.npix), dim3(VP_THREADS), lds, reinterpret_cast<hipStream_t>(stream), p);
   return launch_status();
 }

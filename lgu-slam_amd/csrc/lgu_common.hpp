@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/lgu_corr.h"
 
 namespace lgu {
@@ -99,9 +101,54 @@ inline int launch_status() {
   return e == hipSuccess ? LGU_OK : (int)e;
 }
 
+// ---- debug knobs -------------------------------------------------------------------
+// The LGU_* environment variables read through env_int() select superseded kernels and A/B settings for the tests and
+// tools/.  They are honoured ONLY when LGU_DEBUG_KNOBS=1 was in the environment when the library was loaded (read once,
+// capi.hip; lgu_debug_knobs_enabled() reports it).  Otherwise env_int() returns the default without touching the
+// environment: a production launch makes no getenv call and a stray LGU_* variable changes nothing.
+bool debug_knobs();   // capi.hip
+
 inline int env_int(const char* name, int dflt) {
+  if (!debug_knobs()) return dflt;
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
+}
+
+// ---- per-device launch state ---------------------------------------------------------
+// A process may drive several devices.  What the launchers cache — "this kernel may use more than 64 KB of dynamic LDS"
+// (an attribute of the function ON A DEVICE) and the device's CU count — is therefore kept per device, in namespace-scope
+// tables (no function-local statics); racing writers store the same values.
+constexpr int kMaxDevices = 64;
+
+inline int current_device() {
+  int d = -1;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : -1;
+}
+
+struct DeviceFlags { std::atomic<unsigned char> done[kMaxDevices]; };
+template <auto Kern> inline DeviceFlags g_lds_attr{};   // one table per kernel instantiation
+
+template <auto Kern>
+inline hipError_t allow_max_dynamic_lds() {
+  const int d = current_device();
+  if (d >= 0 && g_lds_attr<Kern>.done[d].load(std::memory_order_relaxed)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && d >= 0) g_lds_attr<Kern>.done[d].store(1, std::memory_order_relaxed);
+  return e;
+}
+
+inline std::atomic<int> g_cu_count[kMaxDevices];
+
+inline int device_cu_count() {   // CUs of the current device (256 on an MI355X; also the answer when the query fails)
+  const int d = current_device();
+  if (d >= 0) {
+    const int c = g_cu_count[d].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int cus = 0;
+  if (d < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus < 1) return 256;
+  g_cu_count[d].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 
 // LGU_LDS_PAD (occupancy experiments only, tools/ab_cold.py): extra dynamic LDS per workgroup, clamped to [0, 96 KiB]

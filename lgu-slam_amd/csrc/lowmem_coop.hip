@@ -656,11 +656,7 @@ static int launch_coop(CoParams p, hipStream_t st) {
     const int pad_kb = env_int("LGU_LOWMEM_COOP_LDS_PAD", 0);
     if (pad_kb > 0) lds = lds + (size_t)pad_kb * 1024 <= 160 * 1024 ? lds + (size_t)pad_kb * 1024 : 160 * 1024;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_max_dynamic_lds<&lowmem_coop_kernel<R, KS>>();
   p.tiles_x = (p.W1 + 4 * CO_SB - 1) / (4 * CO_SB);
   p.tiles_y = (p.H1 + 3) / 4;
   const int tiles = p.tiles_x * p.tiles_y;
@@ -676,13 +672,7 @@ static int launch_coop(CoParams p, hipStream_t st) {
   // Fused workgroups in whole rounds over the device's slots (4 resident workgroups per CU), the remainder split by
   // level group so that the last round is made of short units: a call of 2.3 rounds costs ~2.4 instead of 3.
   // LGU_LOWMEM_COOP_SPLIT (debug / A-B only): 0 = all fused, 1 = all split, default = the rule above.
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-      cus = 256;
-    slots = CO_WPS * cus;
-  }
+  const int slots = CO_WPS * device_cu_count();
   const size_t items = p.xcd_map ? (size_t)((p.B + 7) / 8) * 8 * tiles : (size_t)p.B * tiles;
   if (items >= (1u << 30)) return -1;
   const int mode = env_int("LGU_LOWMEM_COOP_SPLIT", -1);

@@ -335,11 +335,7 @@ static int launch_tile(const T* fmap1, const T* fmap2, const float* coords, floa
                        int H1, int W1, int H2, int W2, int C, hipStream_t st) {
   const size_t lds = sizeof(float) * ((size_t)LT_STAGE_FLOATS + LT_PIX * 4 + 8 + LT_PIX * LT_CH * LT_SCMAX);
   auto kern = lowmem_tile_kernel<R, T>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  allow_max_dynamic_lds<&lowmem_tile_kernel<R, T>>();
   const int tiles_x = (W1 + LT_W - 1) / LT_W, tiles_y = (H1 + LT_H - 1) / LT_H;
   hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * tiles_x * tiles_y), (unsigned)S), dim3(LT_WAVES * kWave), lds, st,
                      fmap1, fmap2, coords, offset, corr, B, S, H1, W1, H2, W2, C, tiles_x, tiles_y);

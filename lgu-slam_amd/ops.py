@@ -82,6 +82,28 @@ def _stream(t):
     return _vp(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+class _CurrentDevice:
+    """Launch guard of the prepared plans: the library launches on the CURRENT device, so a plan whose buffers live on
+    another device switches for the call — and costs one integer comparison when it already is current (the usual
+    one-process-per-GPU case)."""
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+            self.prev = -1
+        return False
+
+
 def _ptr(t):
     return _vp(t.data_ptr())
 
@@ -314,6 +336,7 @@ class LowmemPyramidPlan:
         _, self.H1, self.W1, self.C = fmap1.shape
         self.B = fmap1.shape[0] if ii is None else ii.shape[0]
         self.device = fmap1.device
+        self._guard = _CurrentDevice(self.device)
         self.NO = max([o.shape[0] for o in offsets if o is not None] or [max(self.B, 1)])
         self._f2 = (_vp * L)(*[f.data_ptr() for f in fmap2s])
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
@@ -358,14 +381,16 @@ class LowmemPyramidPlan:
         if self._rows is not None:
             if S != 1:
                 raise RuntimeError("LowmemPyramidPlan: off_row serves one sample per pixel")
-            rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B,
-                          H1, W1, self._h2, self._w2, self.C, self.NO, self._rows, self.radius, self._ii, self._jj,
-                          self._chunked, torch.cuda.current_stream(self.device).cuda_stream)
+            with self._guard:
+                rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B,
+                              H1, W1, self._h2, self._w2, self.C, self.NO, self._rows, self.radius, self._ii, self._jj,
+                              self._chunked, torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(rc, "lowmem_pyramid_forward (several calls)")
             return out
-        rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B, S,
-                      H1, W1, self._h2, self._w2, self.C, self.NO, self.radius, self._ii, self._jj,
-                      torch.cuda.current_stream(self.device).cuda_stream)
+        with self._guard:
+            rc = self._fn(self._keep[0].data_ptr(), self._f2, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.lbase, B, S,
+                          H1, W1, self._h2, self._w2, self.C, self.NO, self.radius, self._ii, self._jj,
+                          torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(rc, "lowmem_pyramid_forward")
         return out
 
@@ -823,6 +848,7 @@ class DefcorrPyramidPlan:
             self.E = slots.shape[0]
         self._slots = slots.data_ptr() if slots is not None and slots.numel() else None
         self.device = volumes[0].device
+        self._guard = _CurrentDevice(self.device)
         self.channels = L * (2 * radius + 1) ** 2
         self._vp = (_vp * L)(*[v.data_ptr() for v in volumes])
         self._op = (_vp * L)(*[(o.data_ptr() if o is not None else None) for o in offsets])
@@ -841,15 +867,16 @@ class DefcorrPyramidPlan:
         if self.E == 0:
             return out
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if self._enc is not None:
-            rc = self._fn_enc(self._vp, self._slots, coords.data_ptr(), self._op, self._enc[0].data_ptr(),
-                              self._enc[1].data_ptr(), out.data_ptr(), self.L, self.E, self.H1, self.W1, self._h2, self._w2,
-                              self.radius, ENC_N, self.flags, st)
-        elif self._slots is not None:
-            rc = self._fn_slots(self._vp, self._slots, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1,
-                                self.W1, self._h2, self._w2, self.radius, self.flags, st)
-        else:
-            rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
-                          self._h2, self._w2, self.radius, self.flags, st)
+        with self._guard:
+            if self._enc is not None:
+                rc = self._fn_enc(self._vp, self._slots, coords.data_ptr(), self._op, self._enc[0].data_ptr(),
+                                  self._enc[1].data_ptr(), out.data_ptr(), self.L, self.E, self.H1, self.W1, self._h2, self._w2,
+                                  self.radius, ENC_N, self.flags, st)
+            elif self._slots is not None:
+                rc = self._fn_slots(self._vp, self._slots, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1,
+                                    self.W1, self._h2, self._w2, self.radius, self.flags, st)
+            else:
+                rc = self._fn(self._vp, coords.data_ptr(), self._op, out.data_ptr(), self.L, self.E, self.H1, self.W1,
+                              self._h2, self._w2, self.radius, self.flags, st)
         _lib.check(rc, "defcorr_pyramid_forward")
         return out

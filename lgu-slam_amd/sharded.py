@@ -294,17 +294,24 @@ def replicas_agree(*tensors, group=None):
 
 
 def sharded_ba(edges, target_local, weight_local, poses, disps, intrinsics, disps_sens, eta, ii, jj, t0, t1,
-               iterations, lm, ep, motion_only, check_replicas=False):
+               iterations, lm, ep, motion_only, check_replicas=False, target=None, weight=None):
     """The dense-BA step of a sharded update (reference factor_graph.py:290-300 after update_lowmem's chunk loop):
     every rank contributes the `target` / `weight` (n_local,2,ht,wd) of the edges it owns (in `edges.my_edges`
     order); ONE all-gather each restores the full (E,2,ht,wd) tensors in the original edge order on every rank, and the
     bundle adjustment (lgu_slam_amd.ba.ba) then runs replicated — identical inputs, deterministic kernels, so every
     rank holds the same updated `poses` / `disps` without a broadcast.  `eta` must be the replicated per-frame damping
     (after ShardedEdgeSet.gather_frames / sharded_update_step); check_replicas=True verifies that and the gathered
-    tensors across ranks before the solve (one scalar all-reduce pair) and raises on a mismatch."""
+    tensors across ranks before the solve (one scalar all-reduce pair) and raises on a mismatch.
+    target / weight (optional, (E,2,ht,wd), replicated): the persistent per-edge state the gathered rows are written INTO.
+    Needed when the edge set leaves edges unprocessed (source frames beyond the reference's `range(0, jj.max()+1, 8)`
+    loop bound, factor_graph.py:273): those edges enter the BA with their PREVIOUS target / weight, as in the reference,
+    and that previous value lives in these tensors; without them such a graph is refused."""
     from . import ba as _ba
-    target = edges.gather(target_local).contiguous()
-    weight = edges.gather(weight_local).contiguous()
+    if (target is None or weight is None) and edges.unprocessed.numel():
+        raise ValueError("sharded_ba: %d edges belong to no chunk of the reference's loop and keep their previous target / weight: "
+                         "pass the persistent target= / weight= tensors" % edges.unprocessed.numel())
+    target = edges.gather(target_local, out=target).contiguous()
+    weight = edges.gather(weight_local, out=weight).contiguous()
     if check_replicas and not replicas_agree(eta, target, weight, poses, disps, group=edges.exchange.group):
         raise RuntimeError("sharded_ba: replicated inputs differ across ranks (eta / target / weight / poses / disps)")
     return _ba.ba(poses, disps, intrinsics, disps_sens, target, weight, eta, ii, jj, t0, t1, iterations, lm, ep, motion_only)
@@ -322,8 +329,11 @@ def sharded_ba_split(edges, target_local, weight_local, poses, disps, intrinsics
       all-gather   of the depth-frame owners' updated disparity rows.
     `target_local` / `weight_local` (n_local,2,ht,wd): this rank's edges in `edges.my_edges` order — the per-edge
     all-gathers of exchange_step are not needed for the BA at all.  `eta_by_frame` (num_frames,ht,wd): damping indexed by
-    frame id; only the rows of owned frames are read, so the per-frame all-gather is not needed either.  Frames without
-    any edge get the same (edge-free) update on every rank.  Results equal the replicated BA up to summation order (the
+    frame id; only the rows of frames this rank owns, and of frames NO rank owns (no edge anywhere: the same edge-free
+    update on every rank, so those rows must be replicated), are used — the rows of frames owned by other ranks may
+    hold anything (stale, zero, NaN): they are replaced by 1 before the depth system, where this rank has no block of
+    such a frame (E = 0, w = 0: its contribution 0 * Q stays 0 instead of 0 * inf).  The per-frame all-gather is
+    therefore not needed.  Results equal the replicated BA up to summation order (the
     system is summed per rank first); every rank holds bit-identical poses / disps afterwards.  World 1 = ba.ba."""
     from . import ba as _ba
     if edges.unprocessed.numel():
@@ -350,6 +360,13 @@ def sharded_ba_split(edges, target_local, weight_local, poses, disps, intrinsics
         if live:
             edges.gather_frames(d[edges.my_frames].contiguous(), out=d)
 
+    eta_safe = eta_by_frame
+    if live:
+        foreign = torch.zeros(eta_by_frame.shape[0], dtype=torch.bool, device=eta_by_frame.device)
+        for r, fr in enumerate(edges.frames):
+            if r != edges.rank and fr.numel():
+                foreign[fr.to(foreign.device)] = True
+        eta_safe = torch.where(foreign.view(-1, *([1] * (eta_by_frame.dim() - 1))), torch.ones_like(eta_by_frame), eta_by_frame)
     return _ba.ba(poses, disps, intrinsics, disps_sens, target_local.contiguous(), weight_local.contiguous(),
-                  lambda kx: eta_by_frame[kx], ii_o, jj_o, t0, t1, iterations, lm, ep, motion_only,
+                  lambda kx: eta_safe[kx], ii_o, jj_o, t0, t1, iterations, lm, ep, motion_only,
                   _hooks=(reduce_system, after_depth))

@@ -36,3 +36,23 @@ def test_no_torch_types_in_the_abi():
     text = open(os.path.join(ROOT, "include", "lgu_corr.h")).read()
     assert "torch" not in text.replace("torch::zeros", "").replace("PyTorch", "").lower().replace("pytorch", "")
     assert "#include" not in text  # plain C, self-contained
+
+
+def test_debug_knobs_are_gated_at_load_time(lgu):
+    """The LGU_* debug variables are honoured only when LGU_DEBUG_KNOBS=1 was set when the library was loaded: a
+    production process (gate unset) never reads the environment, whatever stray LGU_* variables it inherits."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); lib.lgu_version.restype = ctypes.c_char_p; "
+            "print(lib.lgu_debug_knobs_enabled(), lib.lgu_version().decode())")
+    env = {k: v for k, v in os.environ.items() if k != "LGU_DEBUG_KNOBS"}
+    env["LGU_DEFCORR_VARIANT"] = "2"     # a stray knob alone opens nothing
+    off = subprocess.run([sys.executable, "-c", code, lgu._lib._build.SO_PATH], env=env, capture_output=True, text=True, check=True)
+    assert off.stdout.split()[0] == "0", off.stdout
+    for val, want in (("1", "1"), ("0", "0"), ("yes", "0")):
+        on = subprocess.run([sys.executable, "-c", code, lgu._lib._build.SO_PATH], env=dict(env, LGU_DEBUG_KNOBS=val),
+                            capture_output=True, text=True, check=True)
+        assert on.stdout.split()[0] == want, (val, on.stdout)
+    # the in-tree library is the default build: no experiment flags in its version string
+    assert "[" not in off.stdout and "gfx950" in off.stdout
+    assert lgu._lib.debug_knobs_enabled()   # this (test) process asked for them in conftest.py

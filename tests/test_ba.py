@@ -194,6 +194,27 @@ def test_sharded_ba_world1_equals_plain_ba(lgu):
     b = lgu.sharded.sharded_ba(edges, td[edges.my_edges].contiguous(), wd_[edges.my_edges].contiguous(), p2, d2, args[0], args[1], ed,
                                iid, jjd, 1, len(p), 2, 1e-4, 0.1, False)
     assert torch.equal(p1, p2) and torch.equal(d1, d2) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # the reference's loop bound range(0, jj.max()+1, chunk) (factor_graph.py:273) leaves the edges of late source frames
+    # unprocessed: they enter the BA with their PREVIOUS target / weight, which live in the persistent tensors
+    cut = int(iid.max()) - 1
+    jj_low = torch.clamp(jjd, max=cut - 1)                      # bound = cut: source frames >= cut have no chunk
+    edges_u = lgu.sharded.ShardedEdgeSet(iid, rank=0, world=1, chunk=4, jj=jj_low)
+    assert edges_u.unprocessed.numel() > 0
+    own_u = edges_u.my_edges
+    with pytest.raises(ValueError, match="previous target"):
+        lgu.sharded.sharded_ba(edges_u, td[own_u].contiguous(), wd_[own_u].contiguous(), p2, d2, args[0], args[1], ed, iid, jjd, 1,
+                               len(p), 2, 1e-4, 0.1, False)
+    t_state, w_state = td.clone(), wd_.clone()                  # previous values of every edge
+    t_new, w_new = td * 1.01, wd_ * 0.9                         # this step's results for the processed edges
+    p3, d3 = _to_dev(p, d)
+    p4, d4 = _to_dev(p, d)
+    lgu.sharded.sharded_ba(edges_u, t_new[own_u].contiguous(), w_new[own_u].contiguous(), p3, d3, args[0], args[1], ed, iid, jjd, 1,
+                           len(p), 2, 1e-4, 0.1, False, target=t_state, weight=w_state)
+    t_want, w_want = td.clone(), wd_.clone()
+    t_want[own_u], w_want[own_u] = t_new[own_u], w_new[own_u]
+    assert torch.equal(t_state, t_want) and torch.equal(w_state, w_want)
+    lgu.ba.ba(p4, d4, args[0], args[1], t_want, w_want, ed, iid, jjd, 1, len(p), 2, 1e-4, 0.1, False)
+    assert torch.equal(p3, p4) and torch.equal(d3, d4)
 
 
 def _split_ba_worker(rank, world, port, q):
@@ -217,7 +238,11 @@ def _split_ba_worker(rank, world, port, q):
         assert edges.world == world and 0 < edges.counts[rank] < len(ii)
         p1, d1 = _to_dev(p, d)
         own = edges.my_edges
-        out = lgu.sharded.sharded_ba_split(edges, td[own].contiguous(), wd_[own].contiguous(), p1, d1, intr_d, sens, ed, iid, jjd,
+        # only the owner's damping rows (and those of frames nobody owns) are read: the rows of the OTHER rank's frames
+        # hold garbage here (0 * inf = NaN would be all-reduced into every rank's system)
+        ed_local = ed.clone()
+        ed_local[edges.frames[1 - rank]] = float("nan") if rank == 0 else 0.0
+        out = lgu.sharded.sharded_ba_split(edges, td[own].contiguous(), wd_[own].contiguous(), p1, d1, intr_d, sens, ed_local, iid, jjd,
                                            t0, len(p), 2, 1e-4, 0.1, False)
         p2, d2 = _to_dev(p, d)
         kx = torch.unique(torch.cat([torch.arange(t0, len(p), device=iid.device), iid]))

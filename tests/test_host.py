@@ -153,6 +153,47 @@ def test_bench_distributed_control_flow_gloo_world2():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["exchange"]["bytes_per_rank"] == 20 * 48 * 64 * 4 * 4
     for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
         assert k in d
+    sc = d["strong_scaling_config5"]
+    assert sc["n_gpus"] == 2 and sc["replicas_agree"] and sc["every_edge_owned"] and sum(sc["edges_per_rank"]) == sc["edges_total"]
+
+
+def _run_bench(argv, env_drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300,
+                          cwd=ROOT, env=env)
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_command():
+    """`python bench.py --gpus 2` with NO launcher around it (VERDICT r02 missing #3: it used to run one rank silently and
+    print n_gpus 1): the parent starts the two ranks itself, relays rank 0's single JSON line, and the line's n_gpus is
+    the number of ranks the process group initialised.  It also carries the config-5 strong-scaling leg's record."""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["exchange"]["bytes_per_rank"] == 20 * 48 * 64 * 4 * 4
+    sc = d["strong_scaling_config5"]
+    assert sc["n_gpus"] == 2 and sc["replicas_agree"] and sc["every_edge_owned"] and min(sc["edges_per_rank"]) > 0
+    # N = 1: no launcher, no process group, one line
+    one = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "0", "--dry-run-cpu"])
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and "exchange" not in d1 and d1["config5_backend_n1"]["n_gpus"] == 1
+
+
+def test_bench_exits_nonzero_when_a_rank_fails():
+    """A failing rank must fail the whole command (no line, non-zero status), whoever launched it."""
+    out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run-cpu", "--edges", "-1"])
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # and a launcher whose world disagrees with --gpus is refused instead of silently measuring something else
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
 
 
 def test_sharded_edge_set_world1_orders(lgu):

@@ -4,6 +4,8 @@ bench.py's headline): configs x rounds, HIP-event time per launch, median / min.
 Usage: ab_cold.py [variants, default "0,6"] [rounds] [layouts, default "tiled,rowmajor"] [probe values, default "0,1"]"""
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import numpy as np

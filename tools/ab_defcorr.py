@@ -3,6 +3,8 @@
 (cdna_hip_programming.md rule 24): N configs x M rounds, HIP-event time per launch, median/min."""
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import numpy as np

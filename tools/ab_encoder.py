@@ -11,6 +11,8 @@ the largest difference of the encoder output against the planar/fp32-input run.
 import argparse
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import torch

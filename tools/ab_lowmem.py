@@ -4,6 +4,8 @@ for settings "MT[:c]" given on the command line (default "1,2"; MT = LGU_LOWMEM_
 layout), interleaved in one process."""
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import numpy as np

@@ -4,6 +4,8 @@ maps) over environment settings given as "NAME=V,NAME=V;NAME=V;..." (";" separat
 Device time per call, median of 5 rounds of 20 calls each."""
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import numpy as np

@@ -8,6 +8,8 @@ import csv
 import glob
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,6 +9,8 @@ Also times the other operators at representative shapes.  Prints JSON lines.
 import importlib.util
 import json
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import torch

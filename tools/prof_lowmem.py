@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Driver for rocprofv3 runs of the low-memory path (BASELINE config 4 shapes: 60x80, C=128, B=16)."""
 import os
+
+os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel variants through the library's debug variables
 import sys
 
 import torch
