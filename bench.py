@@ -1040,7 +1040,8 @@ def glue_extras(lgu, dev, args):
                 if it >= 4:
                     times.append(e0.elapsed_time(e1))
             # the fused volume post-processing launch alone (gaussianMask + /denominator + corr + 3 poolings: a5 + f1)
-            mean_n, cov, det = GA.gaussian_parameters(blk.t)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                mean_n, cov, det = GA.gaussian_parameters(blk.t)
             raw = lgu.CorrBlock.corr(a, b).view(E, h, w, h, w)
             raw = raw.contiguous() if half else raw.float().contiguous()
             vp = []
@@ -1049,7 +1050,7 @@ def glue_extras(lgu, dev, args):
                 e0, e1 = _events()
                 e0.record()
                 lgu.ops.volume_pyramid(mean_n.float().contiguous(), cov.float().contiguous(), src, 4, 4, inplace=True, tiled=True,
-                                       det=det.contiguous())
+                                       det=det.contiguous() if det.dtype in (torch.float32, torch.float16) else det.float().contiguous())
                 e1.record()
                 e1.synchronize()
                 if it >= 2:

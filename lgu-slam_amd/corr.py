@@ -62,11 +62,15 @@ def per_Corr_Normalization(x, normalIndex, eps=1e-5):
     return (x - mean) / std
 
 
-HEAD_CACHE = os.environ.get("LGU_HEAD_CACHE", "1") != "0"   # debug / A-B only: 0 = one convolution per edge and call
-HEAD_CACHE_MAX_BYTES = 1 << 30   # the per-frame partial convolutions (4.7 MB per 48 x 64 frame for both heads) are kept only
-                                 # while they fit this budget for the WHOLE frame buffer the block was given (update_lowmem
-                                 # hands over video.fmaps: 512 frames would be 2.4 GB); beyond it the heads are convolved per
-                                 # edge (ops.offset_conv_frames), which needs no per-frame state
+# Per-frame partial convolutions of the offset heads, cached per block (ops.OffsetHeadCache).  OFF by default
+# since the fast path convolves only the first edge of a call (LAZY_OFFSETS, §3.4d): that edge's two frames are not met again
+# within the block's life, so the cache would hold 2 x 98 x H x W floats per frame of the WHOLE buffer the block was given
+# (update_lowmem hands over video.fmaps: 2.4 GB at 512 frames of 48 x 64) for nothing.  A caller that reads every edge's
+# offsets over a long-lived block (LAZY_OFFSETS = False) can turn it on; it is then used while it fits HEAD_CACHE_MAX_BYTES and
+# the heads are convolved per edge (ops.offset_conv_frames, no per-frame state) beyond that.  Both forms sum in different
+# orders (equal to 2e-5 in the offsets): one setting serves every call of a block, so lazy and eager calls stay bit-identical.
+HEAD_CACHE = os.environ.get("LGU_HEAD_CACHE", "0") == "1"
+HEAD_CACHE_MAX_BYTES = 1 << 30
 FUSED_OFFSETS = True   # False: the reference-shaped torch composition below also in inference (A/B and tests)
 
 
@@ -501,7 +505,7 @@ class AltCorrBlock:
                 return ops.lowmem_pyramid_forward_mixed(frames[0], [self._chunked[1]], cs, [None], 1, ii=i_, jj=j_, lbase=1,
                                                         chunked=True)
 
-            firsts = self._offsets_from_frames(1, i0, j0, probe=probe_of(c0[first], i0, j0), store=False, per_frame=False)
+            firsts = self._offsets_from_frames(1, i0, j0, probe=probe_of(c0[first], i0, j0), store=False)
             if firsts is False:
                 return one_by_one()
             rows, zero_level = firsts
@@ -519,16 +523,13 @@ class AltCorrBlock:
         out = fused.view(1, E, -1, H, W)
         return out if squeeze else out.unsqueeze(-1)
 
-    def _offsets_from_frames(self, B, ii, jj, probe=None, store=True, per_frame=True):
+    def _offsets_from_frames(self, B, ii, jj, probe=None, store=True):
         """Inference fast path of the offset heads for a half pyramid (update_lowmem's case, autocast off): both heads
         run on the matrix cores straight from stored frames (ops.offset_conv_frames: no gather / x 4 / cat / cast of a
         (E,256,H,W) tensor, fp32-accurate split-half weights).  The residual head's input, the 2 x 2 average of the
         frames, is pooled ONCE per block instead of per call (the same fp32 averages of the same numbers: pooling
         commutes with the per-edge gather) and split into two half parts.  The rest is finish_offsets.  Sets
-        self.offset; returns False when the general composition has to run.
-        per_frame=False: convolve per edge, without the per-frame partial-convolution cache — what the first-edge-only
-        calls ask for (one edge per chunk: its two frames are not met again within the block's life, so the cache would
-        hold 2 x 98 x H x W floats per frame of the buffer for nothing)."""
+        self.offset; returns False when the general composition has to run."""
         conv = self.ofsMap
         C = self.pyramid[0].shape[-1]
         if not (FUSED_OFFSETS and B == 1 and self.num_levels >= 2 and self.pyramid[0].dtype == torch.float16
@@ -570,7 +571,7 @@ class AltCorrBlock:
         try:
             nf, hh, ww = frames0.shape[0], frames0.shape[1], frames0.shape[2]
             cache_bytes = 2 * 4 * nf * conv.out_channels * (hh * ww + (hh // 2) * (ww // 2))
-            if HEAD_CACHE and per_frame and res_fast and C % 64 == 0 and cache_bytes <= HEAD_CACHE_MAX_BYTES:
+            if HEAD_CACHE and res_fast and C % 64 == 0 and cache_bytes <= HEAD_CACHE_MAX_BYTES:
                 # per-frame partial convolutions, kept for the life of this block (ops.OffsetHeadCache): the heads are
                 # linear in cat(frame ii, frame jj), a frame is source / target of ~10 edges each and the block serves
                 # every chunk of an update_lowmem pass, so each frame is convolved once and an edge costs a sum
@@ -661,7 +662,7 @@ class AltCorrBlock:
             # Only the first edge's offsets are ever read (class docstring): probe, heads, post-processing for that edge.
             try:
                 i0, j0 = iic[:1], jjc[:1]
-                first = self._offsets_from_frames(B, i0, j0, probe=run_probe(1), store=False, per_frame=False)
+                first = self._offsets_from_frames(B, i0, j0, probe=run_probe(1), store=False)
                 if first is not False:
                     rows, zero_level = first
                     offs = [None if zero_level[i] else rows[i].contiguous().view(1, H, W, rd, rd, 2).float()

@@ -291,33 +291,48 @@ __global__ __launch_bounds__(NWV* kWave, 6) void defcorr_lean_kernel(
   // ---- phase B: blend in the reference's order (:83-86), park in the transpose tile ----
   const unsigned lrow = lane * (PITCH * 4u) + w * (GP * 4u);   // byte address of (channel = lane, pixel = w * GP)
   char* const lds = reinterpret_cast<char*>(outst);
+  auto blend_offset_level = [&](int k, int l) __attribute__((always_inline)) {
+    const bool sh = gshift[k][l];
+    const float q11 = sh ? qa[k][l].y : qa[k][l].x;
+    const float q12r = sh ? qb[k][l].y : qb[k][l].x;
+    const float q21 = sh ? qc[k][l] : qa[k][l].y;        // out-of-range corners read as 0 (:76-80)
+    const float q22r = sh ? qd[k][l] : qb[k][l].y;
+    const float q12 = gyin[k][l] ? q12r : 0.0f;
+    const float q22 = gyin[k][l] ? q22r : 0.0f;
+    const float val = gvalid[k][l] ? bilerp(q11, q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
+    if (tap) *reinterpret_cast<float*>(lds + lrow + (l * NT * PITCH + k) * 4) = val;
+  };
+  auto blend_lattice_level = [&](int k, int l) __attribute__((always_inline)) {   // l = 2, 3
+    const int x1 = lfx[k][l - 2] + tix, y1 = lfy[k][l - 2] + tjy;
+    const int lv = __builtin_bit_cast(int, latin[k][l - 2] ? latv[k][l - 2] : 0.0f);
+    const float q11 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4, lv));
+    const float q21 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 4, lv));
+    const float q12 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 32, lv));
+    const float q22 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 36, lv));
+    // out-of-bounds corners arrive as 0 from the lattice; the whole-tap rule (:60) on top; bilerp()'s sum order
+    const float* wq = lw[k][l - 2];
+    const float val = ((unsigned)x1 < (unsigned)g.W2[l] && (unsigned)y1 < (unsigned)g.H2[l])
+                          ? q11 * wq[0] + q21 * wq[1] + q12 * wq[2] + q22 * wq[3] : 0.0f;
+    if (tap) *reinterpret_cast<float*>(lds + lrow + (l * NT * PITCH + k) * 4) = val;
+  };
+  if constexpr (PROBE) {
+    // level 1 was requested last, behind the probe -> mask chain: everything else is blended while it travels
 #pragma unroll
-  for (int k = 0; k < GP; k++) {
+    for (int k = 0; k < GP; k++) blend_offset_level(k, 0);
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-      const bool sh = gshift[k][l];
-      const float q11 = sh ? qa[k][l].y : qa[k][l].x;
-      const float q12r = sh ? qb[k][l].y : qb[k][l].x;
-      const float q21 = sh ? qc[k][l] : qa[k][l].y;        // out-of-range corners read as 0 (:76-80)
-      const float q22r = sh ? qd[k][l] : qb[k][l].y;
-      const float q12 = gyin[k][l] ? q12r : 0.0f;
-      const float q22 = gyin[k][l] ? q22r : 0.0f;
-      const float val = gvalid[k][l] ? bilerp(q11, q21, q12, q22, gdx[k][l], gdy[k][l]) : 0.0f;
-      if (tap) *reinterpret_cast<float*>(lds + lrow + (l * NT * PITCH + k) * 4) = val;
+    for (int k = 0; k < GP; k++) {
+      blend_lattice_level(k, 2);
+      blend_lattice_level(k, 3);
     }
 #pragma unroll
-    for (int l = 2; l < NL; l++) {
-      const int x1 = lfx[k][l - 2] + tix, y1 = lfy[k][l - 2] + tjy;
-      const int lv = __builtin_bit_cast(int, latin[k][l - 2] ? latv[k][l - 2] : 0.0f);
-      const float q11 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4, lv));
-      const float q21 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 4, lv));
-      const float q12 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 32, lv));
-      const float q22 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)lsrc4 + 36, lv));
-      // out-of-bounds corners arrive as 0 from the lattice; the whole-tap rule (:60) on top; bilerp()'s sum order
-      const float* wq = lw[k][l - 2];
-      const float val = ((unsigned)x1 < (unsigned)g.W2[l] && (unsigned)y1 < (unsigned)g.H2[l])
-                            ? q11 * wq[0] + q21 * wq[1] + q12 * wq[2] + q22 * wq[3] : 0.0f;
-      if (tap) *reinterpret_cast<float*>(lds + lrow + (l * NT * PITCH + k) * 4) = val;
+    for (int k = 0; k < GP; k++) blend_offset_level(k, 1);
+  } else {
+#pragma unroll
+    for (int k = 0; k < GP; k++) {
+      blend_offset_level(k, 0);
+      blend_offset_level(k, 1);
+      blend_lattice_level(k, 2);
+      blend_lattice_level(k, 3);
     }
   }
   __syncthreads();

@@ -162,6 +162,9 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 #ifndef CO_PRIO
 #define CO_PRIO 0
 #endif
+#ifndef CO_ST2
+#define CO_ST2 0
+#endif
 constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
 __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const CoParams p_arg) {
@@ -505,6 +508,28 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
               const int yg = y * CO_BOXP + gq;  // scalar
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) {
+#if CO_ST2
+                // The two predicated pair stores of a sub-block with exec set directly from (row mask & column mask): the wave
+                // is whole and its control flow uniform here, so exec is all ones on entry and is put back to all ones — three
+                // scalar instructions instead of the and / saveexec / restore triple the compiler builds around EACH store.
+                {
+                  typedef float cof32x2 __attribute__((ext_vector_type(2)));
+                  const cof32x2 dlo = {d[m][0], d[m][1]}, dhi = {d[m][2], d[m][3]};
+                  const unsigned da = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(sbp[m] + yg);
+                  asm volatile(
+                      "v_cmp_lt_u32 vcc, %[rr], %[bh]\n\t"
+                      "s_and_b64 exec, vcc, %[ca]\n\t"
+                      "ds_write_b64 %[da], %[lo]\n\t"
+                      "s_and_b64 exec, vcc, %[cb]\n\t"
+                      "ds_write_b64 %[da], %[hi] offset:8\n\t"
+                      "s_mov_b64 exec, -1"
+                      :
+                      : [rr] "v"((unsigned)(y - sylo[m])), [bh] "v"((unsigned)sbh[m]), [ca] "s"(colA[m]), [cb] "s"(colB[m]),
+                        [da] "v"(da), [lo] "v"(dlo), [hi] "v"(dhi)
+                      : "vcc", "memory");
+                }
+                continue;
+#endif
                 const unsigned long long rowm = __builtin_amdgcn_ballot_w64((unsigned)(y - sylo[m]) < (unsigned)sbh[m]);
                 float* dst = sbp[m] + yg;
 #ifdef CO_ABL_STORES  // ablation (timing only): a store only where no lane passes
@@ -532,68 +557,88 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
     __syncthreads();
 
     // ---- phase 2: sample the patches of the wave's own pixels ----
+    // Straight-line for the pixels that have a patch (all of them, in practice): every patch read of a pass is issued
+    // before the first blend.  A pixel WITHOUT a patch — outside the image, non-finite coords, or a box larger than a
+    // patch (per-tap fallback) — reads its own patch's first entries instead (a legal address) and is put right
+    // afterwards, behind a wave-uniform branch that is not taken unless some lane of the wave is such a pixel: left inside
+    // the tap loop, that rare path turns every tap into a chain of exec-mask branches with a wait behind each read.
     float res[CO_QP][TI];
     {
       CO_FRESH_LANE();
-      int tix[TI], tiy[TI];  // lanes past the last tap repeat it (their results are not stored)
+      int trel[TI];  // (tap row - R) * pitch + (tap column - R); lanes past the last tap repeat it (their results are not stored)
 #pragma unroll
       for (int i = 0; i < TI; i++) {
         int t = lx + 16 * i;
         t = t < NT ? t : NT - 1;
-        tix[i] = t / RD;
-        tiy[i] = t - tix[i] * RD;
+        const int ix = t / RD;
+        trel[i] = (t - ix * RD - R) * CO_BOXP + (ix - R);
       }
 #pragma unroll
       for (int q = 0; q < CO_QP; q++) {
         const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
-        const int4 pb = *reinterpret_cast<const int4*>(pbox + (msb * 16 + (qr0 + q) * 4 + lg) * 4);  // row-uniform
+        const int pixl = msb * 16 + (qr0 + q) * 4 + lg;
+        const int4 pb = *reinterpret_cast<const int4*>(pbox + pixl * 4);  // row-uniform
 #ifdef CO_ABL_SAMPLE   // ablation (timing only): no patch reads in the sampling phase
         const bool has_patch = pb.w == 12345, fallback = false;
 #else
         const bool has_patch = pb.w != 0, fallback = pb.z < 0;
 #endif
+        const bool odd = __builtin_amdgcn_ballot_w64(!has_patch) != 0;  // wave-uniform
         // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
-        const float* const D0 = patch + (msb * 16 + (qr0 + q) * 4 + lg) * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
+        const int d0 = pixl * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
 #if CO_OFRESH
         if (!zo && lx == CEN % 16) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap, as phase 0 left it (:80-81)
 #endif
+        float q11[TI], q21[TI], q12[TI], q22[TI];  // all reads of the pass in flight before the first blend
         if (zo) {
           // one sample position per pixel: floor, fraction and the four weights once per pass (products and order are bilerp()'s)
           const float zfx = floorf(cx), zfy = floorf(cy);
           const float zdx = cx - zfx, zdy = cy - zfy;
           const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
-          const float* const Dz = D0 + ((int)zfy - R) * CO_BOXP + ((int)zfx - R);
-          float q11[TI], q21[TI], q12[TI], q22[TI];  // all reads of the pass in flight before the first blend
+          const int dz = has_patch ? d0 + (int)zfy * CO_BOXP + (int)zfx : pixl * CO_PP + R * CO_BOXP + R;  // one select per pass
 #pragma unroll
           for (int i = 0; i < TI; i++) {
-            q11[i] = q21[i] = q12[i] = q22[i] = 0.f;
-            if (has_patch) {
-              const float* D = Dz + tiy[i] * CO_BOXP + tix[i];
-              q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
-            }
+            const float* D = patch + dz + trel[i];
+            q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
           }
 #pragma unroll
           for (int i = 0; i < TI; i++) res[q][i] = q11[i] * zw11 + q21[i] * zw21 + q12[i] * zw12 + q22[i] * zw22;
+          if (odd) {
+            asm volatile("");  // a real (scalar) branch
+#pragma unroll
+            for (int i = 0; i < TI; i++) res[q][i] = has_patch ? res[q][i] : 0.f;
+          }
         } else {
-          float q11[TI], q21[TI], q12[TI], q22[TI], dxs[TI], dys[TI];
+          float dxs[TI], dys[TI];
 #pragma unroll
           for (int i = 0; i < TI; i++) {
             const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;
             const float fxs = floorf(xs), fys = floorf(ys);
             dxs[i] = xs - fxs; dys[i] = ys - fys;  // :87-88
-            const int w2 = (int)fxs - R + tix[i], h2 = (int)fys - R + tiy[i];
-            q11[i] = q21[i] = q12[i] = q22[i] = 0.f;
-            if (has_patch) {
-              const float* D = D0 + h2 * CO_BOXP + w2;
-              q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
-            } else if (fallback) {  // box larger than a patch: this tap's four corner dots, channels in order, per-corner zero padding
-              const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
-              const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
-              const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
-                                               (by0 && bx0 ? 1 : 0) | (by0 && bx1 ? 2 : 0) | (by1 && bx0 ? 4 : 0) | (by1 && bx1 ? 8 : 0),
-                                               p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
-              q11[i] = qq.x; q21[i] = qq.y; q12[i] = qq.z; q22[i] = qq.w;
+            const int rel = (int)fys * CO_BOXP + (int)fxs + trel[i];
+            const float* D = patch + (has_patch ? d0 + rel : pixl * CO_PP);
+            q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
+          }
+          if (odd) {
+            asm volatile("");  // a real (scalar) branch: the rare pixels of this pass
+#pragma unroll
+            for (int i = 0; i < TI; i++) {
+              if (!has_patch) {
+                q11[i] = q21[i] = q12[i] = q22[i] = 0.f;
+                if (fallback) {  // box larger than a patch: this tap's four corner dots, channels in order, per-corner zero padding
+                  int t = lx + 16 * i;
+                  t = t < NT ? t : NT - 1;
+                  const int ix = t / RD;
+                  const int w2 = (int)floorf(cx + o0[q][i].x) - R + ix, h2 = (int)floorf(cy + o0[q][i].y) - R + (t - ix * RD);
+                  const bool bx0 = (unsigned)w2 < (unsigned)W2, bx1 = (unsigned)(w2 + 1) < (unsigned)W2;
+                  const bool by0 = (unsigned)h2 < (unsigned)H2, by1 = (unsigned)(h2 + 1) < (unsigned)H2;
+                  const float4 qq = co_corner_dots(F1 + ((size_t)h1 * W1 + w1r) * C, F2, (ptrdiff_t)h2 * W2 + w2, C, W2,
+                                                   (by0 && bx0 ? 1 : 0) | (by0 && bx1 ? 2 : 0) | (by1 && bx0 ? 4 : 0) | (by1 && bx1 ? 8 : 0),
+                                                   p.f2_chunked ? EPL : C, p.f2_chunked ? (ptrdiff_t)H2 * W2 * EPL : EPL);
+                  q11[i] = qq.x; q21[i] = qq.y; q12[i] = qq.z; q22[i] = qq.w;
+                }
+              }
             }
           }
 #pragma unroll
@@ -622,15 +667,29 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float* const cb = p.corr + (((size_t)b * S + n) * p.Ltot + p.lvl0 + lvl) * NT * HW1;
-      for (int idx = lane; idx < NT * CO_QP; idx += kWave) {
-        const int t = idx / CO_QP, q = idx - t * CO_QP;
-        const int h1 = by * 4 + qr0 + q, w1 = px0;
-        if (h1 >= H1 || w1 >= W1) continue;
-        const float4 v = *reinterpret_cast<const float4*>(outt + t * CO_OUTP + q * 4);
-        float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
-        if (p.vec_out) {
-          *reinterpret_cast<float4*>(dst) = v;
-        } else {
+      if (p.vec_out) {
+        // 98 (tap, row) items of 4 pixels each: lane -> tap lane / 2 (and 32 taps on: a scalar step of the base), row lane % 2;
+        // one 32-bit lane offset serves both (host-checked: a level's output is below 4 GB)
+        static_assert(CO_QP == 2, "item layout");
+        const int t0 = lane >> 1, qq = lane & 1;
+        const int h1 = by * 4 + qr0 + qq;
+        const unsigned loff = ((unsigned)(t0 * H1 + h1) * (unsigned)W1 + (unsigned)px0) * 4u;
+        const float* const src = outt + t0 * CO_OUTP + qq * 4;
+        if (h1 < H1 && px0 < W1) {
+          const float4 v0 = *reinterpret_cast<const float4*>(src);
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(cb) + (size_t)loff) = v0;
+          if (t0 + 32 < NT) {
+            const float4 v1 = *reinterpret_cast<const float4*>(src + 32 * CO_OUTP);
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(cb + 32 * HW1) + (size_t)loff) = v1;
+          }
+        }
+      } else {   // W1 % 4 != 0 or an unaligned output: element stores with their own range checks
+        for (int idx = lane; idx < NT * CO_QP; idx += kWave) {
+          const int t = idx / CO_QP, q = idx - t * CO_QP;
+          const int h1 = by * 4 + qr0 + q, w1 = px0;
+          if (h1 >= H1 || w1 >= W1) continue;
+          const float4 v = *reinterpret_cast<const float4*>(outt + t * CO_OUTP + q * 4);
+          float* dst = cb + ((size_t)t * H1 + h1) * W1 + w1;
           dst[0] = v.x;
           if (w1 + 1 < W1) dst[1] = v.y;
           if (w1 + 2 < W1) dst[2] = v.z;
@@ -706,7 +765,7 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   uintptr_t al = reinterpret_cast<uintptr_t>(fmap1);
   for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(fmap2[l]);
   if ((al & 15) != 0) return -1;
-  if ((size_t)H1 * W1 * C >= (1u << 31)) return -1;
+  if ((size_t)H1 * W1 * C >= (1u << 31) || (size_t)H1 * W1 * 49 * 4 >= (1ull << 32)) return -1;
   CoParams p = {};
   p.fmap1 = static_cast<const _Float16*>(fmap1);
   for (int l = 0; l < L; l++) {

@@ -1719,7 +1719,7 @@ def test_offset_head_cache_equals_the_per_edge_convolution(lgu):
 
 
 def test_altcorrblock_head_cache_on_and_off(lgu, monkeypatch):
-    """AltCorrBlock with the per-frame head cache (default) and without (corr.HEAD_CACHE = False): two chunks of a graph
+    """AltCorrBlock with the per-frame head cache (corr.HEAD_CACHE = True, opt-in) and without (default): two chunks of a graph
     whose frames overlap give the same lookup (offsets equal to fp32 summation order; the lookup is continuous in them
     away from integer sample positions, so it is compared loosely) and the same offsets closely."""
     torch.manual_seed(12)
@@ -1745,6 +1745,14 @@ def test_altcorrblock_head_cache_on_and_off(lgu, monkeypatch):
                 res.append((c.clone(), [o.clone() for o in blk.offset[:2]]))
         assert hasattr(blk, "_head0") == flag
         outs[flag] = res
+    # the cache is bounded: beyond HEAD_CACHE_MAX_BYTES for the whole frame buffer the heads are convolved per edge
+    monkeypatch.setattr(lgu.corr, "HEAD_CACHE", True)
+    monkeypatch.setattr(lgu.corr, "HEAD_CACHE_MAX_BYTES", 1 << 20)
+    blk = lgu.AltCorrBlock(ofsMap, ofsRes, None, fmaps)
+    with torch.no_grad():
+        blk(coords, *chunks[1])
+        _ = blk.offset
+    assert not hasattr(blk, "_head0")
     for (ca, oa), (cb, ob) in zip(outs[True], outs[False]):
         for x, y in zip(oa, ob):
             assert float((x - y).abs().max()) <= 2e-5
