@@ -1009,8 +1009,8 @@ def extras(args, ops, dev, sets, A, headline_ms):
 def glue_extras(lgu, dev, args):
     """Host-glue costs in the driver-run line: CorrBlock.__init__ at E = 20 (fp32 maps, and half maps
     under autocast as factor_graph.py:90 builds it) with the HBM fraction of its volume post-processing, and
-    AltCorrBlock.__call__ on a 16-edge chunk at 60x80.  Device time by HIP events around whole calls (Python included:
-    these are multi-launch host paths)."""
+    AltCorrBlock.__call__ on a 16-edge chunk at 60x80.  Device time by HIP events around GROUPS of calls issued back to
+    back (multi-launch host paths: a single isolated call would measure Python's launch latency, not the device)."""
     out = {}
     g = torch.Generator(device=dev)
     g.manual_seed(99)
@@ -1029,16 +1029,19 @@ def glue_extras(lgu, dev, args):
         f1_bytes = 16 + h * w * 4 + int(h * w * 4 * (1 + 1 / 4 + 1 / 16 + 1 / 64))
         for half in (False, True):
             a, b = (f1.half(), f2.half()) if half else (f1, f2)
+            # constructions issued back to back, as the frontend issues them between other work: device time of groups
+            # of 5 (the host runs ahead of the device, so this is the device's cost, not the launch latency of ~40 launches)
             times = []
-            for it in range(14):
+            for it in range(6):
                 e0, e1 = _events()
                 e0.record()
-                with torch.autocast("cuda", dtype=torch.float16, enabled=half):
-                    blk = lgu.CorrBlock(ofsMap, ofsRes, GA, a, b)
+                for _ in range(5):
+                    with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                        blk = lgu.CorrBlock(ofsMap, ofsRes, GA, a, b)
                 e1.record()
                 e1.synchronize()
-                if it >= 4:
-                    times.append(e0.elapsed_time(e1))
+                if it >= 1:
+                    times.append(e0.elapsed_time(e1) / 5)
             # the fused volume post-processing launch alone (gaussianMask + /denominator + corr + 3 poolings: a5 + f1)
             with torch.autocast("cuda", dtype=torch.float16, enabled=half):
                 mean_n, cov, det = GA.gaussian_parameters(blk.t)
@@ -1083,14 +1086,15 @@ def glue_extras(lgu, dev, args):
         coords = (torch.stack([xs, ys], -1)[None, None] + 2 * torch.randn(1, 16, H, W, 2, device=dev, generator=g)).contiguous()
         blk = lgu.AltCorrBlock(ofsMap2, ofsRes2, None, fm)
         times = []
-        for it in range(24):
+        for it in range(7):   # groups of 10 calls back to back (the chunk loop of update_lowmem issues them like this)
             e0, e1 = _events()
             e0.record()
-            blk(coords, ii, jj)
+            for _ in range(10):
+                blk(coords, ii, jj)
             e1.record()
             e1.synchronize()
-            if it >= 4:
-                times.append(e0.elapsed_time(e1))
+            if it >= 1:
+                times.append(e0.elapsed_time(e1) / 10)
         ms = float(np.median(times))
         out["altcorrblock_call"] = {"workload": "AltCorrBlock.__call__, 16 edges over 8 frames of 60x80x128 half maps: level-1 probe, offset heads "
                                                 "of the call's first edge + post-processing, fused 4-level low-memory lookup",

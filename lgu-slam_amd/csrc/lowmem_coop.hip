@@ -162,9 +162,6 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
 #ifndef CO_PRIO
 #define CO_PRIO 0
 #endif
-#ifndef CO_ST2
-#define CO_ST2 0
-#endif
 constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
 __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const CoParams p_arg) {
@@ -228,16 +225,19 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
     const float* const ob = level_offsets(l);
     if (!ob) return;
     CO_FRESH_LANE();
+    // Unconditional loads from clamped positions (pixels outside the image read pixel 0, lanes past the last tap read it
+    // again: their values are never used): a load behind a lane condition becomes an exec-mask branch with a full wait for
+    // every outstanding load behind it, which serialises the request with whatever else is in flight.
 #pragma unroll
     for (int q = 0; q < CO_QP; q++) {
       const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
       const bool pv = h1 < H1 && w1r < W1;
-      const size_t pix = pv ? (size_t)h1 * W1 + w1r : 0;
+      const unsigned pixo = pv ? ((unsigned)h1 * (unsigned)W1 + (unsigned)w1r) * (unsigned)(NT * 2 * sizeof(float)) : 0u;  // < 2^32 (host-checked)
 #pragma unroll
       for (int i = 0; i < TI; i++) {
-        const int t = lx + 16 * i;
-        o0[q][i] = make_float2(0.f, 0.f);
-        if (pv && t < NT) o0[q][i] = reinterpret_cast<const float2*>(ob + pix * NT * 2)[t];
+        int t = lx + 16 * i;
+        t = t < NT ? t : NT - 1;
+        o0[q][i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ob) + (size_t)(pixo + (unsigned)t * 8u));
       }
     }
   };
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           sbh[m] = pb.w;                    // 0 = no patch: no row passes
           swl[m] = pb.x + pb.z - 1 - xal;   // last patch column a pair may start at or before
           sq0[m] = TX0 + 4 * lg - xal;      // patch column of this lane's first pair in group 0
-          sbp[m] = patch + (m * 16 + lx) * CO_PP - pb.y * CO_BOXP + sq0[m];
+          sbp[m] = patch + __mul24(m * 16 + lx, CO_PP) - __mul24(pb.y, CO_BOXP) + sq0[m];
         }
         const int ngx = (TX1 - TX0 + 16) >> 4;
         const int y0w = TY0 + wv;
@@ -508,28 +508,6 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
               const int yg = y * CO_BOXP + gq;  // scalar
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) {
-#if CO_ST2
-                // The two predicated pair stores of a sub-block with exec set directly from (row mask & column mask): the wave
-                // is whole and its control flow uniform here, so exec is all ones on entry and is put back to all ones — three
-                // scalar instructions instead of the and / saveexec / restore triple the compiler builds around EACH store.
-                {
-                  typedef float cof32x2 __attribute__((ext_vector_type(2)));
-                  const cof32x2 dlo = {d[m][0], d[m][1]}, dhi = {d[m][2], d[m][3]};
-                  const unsigned da = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(sbp[m] + yg);
-                  asm volatile(
-                      "v_cmp_lt_u32 vcc, %[rr], %[bh]\n\t"
-                      "s_and_b64 exec, vcc, %[ca]\n\t"
-                      "ds_write_b64 %[da], %[lo]\n\t"
-                      "s_and_b64 exec, vcc, %[cb]\n\t"
-                      "ds_write_b64 %[da], %[hi] offset:8\n\t"
-                      "s_mov_b64 exec, -1"
-                      :
-                      : [rr] "v"((unsigned)(y - sylo[m])), [bh] "v"((unsigned)sbh[m]), [ca] "s"(colA[m]), [cb] "s"(colB[m]),
-                        [da] "v"(da), [lo] "v"(dlo), [hi] "v"(dhi)
-                      : "vcc", "memory");
-                }
-                continue;
-#endif
                 const unsigned long long rowm = __builtin_amdgcn_ballot_w64((unsigned)(y - sylo[m]) < (unsigned)sbh[m]);
                 float* dst = sbp[m] + yg;
 #ifdef CO_ABL_STORES  // ablation (timing only): a store only where no lane passes
@@ -585,7 +563,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
 #endif
         const bool odd = __builtin_amdgcn_ballot_w64(!has_patch) != 0;  // wave-uniform
         // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
-        const int d0 = pixl * CO_PP - pb.y * CO_BOXP - (pb.x & ~1);
+        const int d0 = __mul24(pixl, CO_PP) - __mul24(pb.y, CO_BOXP) - (pb.x & ~1);  // 24-bit products: full rate
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
 #if CO_OFRESH
         if (!zo && lx == CEN % 16) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap, as phase 0 left it (:80-81)
@@ -596,7 +574,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           const float zfx = floorf(cx), zfy = floorf(cy);
           const float zdx = cx - zfx, zdy = cy - zfy;
           const float zw11 = (1.0f - zdy) * (1.0f - zdx), zw21 = (1.0f - zdy) * zdx, zw12 = zdy * (1.0f - zdx), zw22 = zdy * zdx;
-          const int dz = has_patch ? d0 + (int)zfy * CO_BOXP + (int)zfx : pixl * CO_PP + R * CO_BOXP + R;  // one select per pass
+          const int dz = has_patch ? d0 + __mul24((int)zfy, CO_BOXP) + (int)zfx : __mul24(pixl, CO_PP) + R * CO_BOXP + R;  // one select per pass
 #pragma unroll
           for (int i = 0; i < TI; i++) {
             const float* D = patch + dz + trel[i];
@@ -616,8 +594,8 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
             const float xs = cx + o0[q][i].x, ys = cy + o0[q][i].y;
             const float fxs = floorf(xs), fys = floorf(ys);
             dxs[i] = xs - fxs; dys[i] = ys - fys;  // :87-88
-            const int rel = (int)fys * CO_BOXP + (int)fxs + trel[i];
-            const float* D = patch + (has_patch ? d0 + rel : pixl * CO_PP);
+            const int rel = __mul24((int)fys, CO_BOXP) + (int)fxs + trel[i];
+            const float* D = patch + (has_patch ? d0 + rel : __mul24(pixl, CO_PP));
             q11[i] = D[0]; q21[i] = D[1]; q12[i] = D[CO_BOXP]; q22[i] = D[CO_BOXP + 1];
           }
           if (odd) {
@@ -765,7 +743,7 @@ int lowmem_coop_dispatch(const void* fmap1, const void* const* fmap2, float* con
   uintptr_t al = reinterpret_cast<uintptr_t>(fmap1);
   for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(fmap2[l]);
   if ((al & 15) != 0) return -1;
-  if ((size_t)H1 * W1 * C >= (1u << 31) || (size_t)H1 * W1 * 49 * 4 >= (1ull << 32)) return -1;
+  if ((size_t)H1 * W1 * C >= (1u << 31) || (size_t)H1 * W1 * 49 * 8 >= (1ull << 32)) return -1;
   CoParams p = {};
   p.fmap1 = static_cast<const _Float16*>(fmap1);
   for (int l = 0; l < L; l++) {

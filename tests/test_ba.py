@@ -196,8 +196,7 @@ def test_sharded_ba_world1_equals_plain_ba(lgu):
     assert torch.equal(p1, p2) and torch.equal(d1, d2) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     # the reference's loop bound range(0, jj.max()+1, chunk) (factor_graph.py:273) leaves the edges of late source frames
     # unprocessed: they enter the BA with their PREVIOUS target / weight, which live in the persistent tensors
-    cut = int(iid.max()) - 1
-    jj_low = torch.clamp(jjd, max=cut - 1)                      # bound = cut: source frames >= cut have no chunk
+    jj_low = torch.clamp(jjd, max=7)                            # bound = 8 -> chunks [0,4), [4,8): source frames >= 8 have no chunk
     edges_u = lgu.sharded.ShardedEdgeSet(iid, rank=0, world=1, chunk=4, jj=jj_low)
     assert edges_u.unprocessed.numel() > 0
     own_u = edges_u.my_edges
