@@ -646,14 +646,14 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float* const cb = p.corr + (((size_t)b * S + n) * p.Ltot + p.lvl0 + lvl) * NT * HW1;
       if (p.vec_out) {
-        // 98 (tap, row) items of 4 pixels each: lane -> tap lane / 2 (and 32 taps on: a scalar step of the base), row lane % 2;
+        // NT x 2 (tap, row) items of 4 pixels each (98 at radius 3): lane -> tap lane / 2 (and 32 taps on: a scalar step of the base), row lane % 2;
         // one 32-bit lane offset serves both (host-checked: a level's output is below 4 GB)
         static_assert(CO_QP == 2, "item layout");
         const int t0 = lane >> 1, qq = lane & 1;
         const int h1 = by * 4 + qr0 + qq;
         const unsigned loff = ((unsigned)(t0 * H1 + h1) * (unsigned)W1 + (unsigned)px0) * 4u;
         const float* const src = outt + t0 * CO_OUTP + qq * 4;
-        if (h1 < H1 && px0 < W1) {
+        if (h1 < H1 && px0 < W1 && t0 < NT) {   // (t0 < NT: radius 1 / 2 have 9 / 25 taps, fewer than the 32 of the first item)
           const float4 v0 = *reinterpret_cast<const float4*>(src);
           *reinterpret_cast<float4*>(reinterpret_cast<char*>(cb) + (size_t)loff) = v0;
           if (t0 + 32 < NT) {

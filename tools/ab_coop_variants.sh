@@ -11,7 +11,9 @@ sel() { if [ "$1" = default ]; then unset LGU_LIB_PATH; else export LGU_LIB_PATH
 for n in "$@"; do
   sel $n
   if [ "${TESTS:-1}" = 1 ]; then
-    echo "== $n tests: $(timeout -k 10 400 python -m pytest tests/test_gpu_parity.py tests/test_glue_reference.py -m gpu -q -x -p no:cacheprovider -k 'coop or lowmem or call_many or config5 or offset_rows or altcorr' 2>&1 | tail -1)"
+    timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_glue_reference.py -m gpu -q -p no:cacheprovider -k 'coop or lowmem or call_many or config5 or offset_rows or altcorr' > gpurun_out/ab_tests_$n.log 2>&1
+    echo "== $n tests: $(tail -1 gpurun_out/ab_tests_$n.log)"
+    grep "^FAILED" gpurun_out/ab_tests_$n.log | cut -c1-200    # every failing case by name: a variant that fails parity is not a candidate
   fi
 done
 for pass in 1 2; do
