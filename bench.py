@@ -396,9 +396,11 @@ def lowmem_roofline(S, dev_ms):
     achieved = flop_unit * S["units"] / kern_s / 1e12
     hbm_unit = (1 + 1.328) * S["C"] * 2 + 784 + 784 + 8  # half maps: fmap1 + fmap2 pyramid, out, offsets of 2 levels, coords
     traffic, tsrc = None, None
-    tfile = os.path.join(ROOT, "profiles", "traffic_r02_lowmem.json")
-    if os.path.exists(tfile) and S["B"] == 16:   # PMC passes of this same command (tools/gpu_lowmem_run.sh)
-        traffic, tsrc = json.load(open(tfile))["hbm_bytes_per_launch"], "profiles/traffic_r02_lowmem.json"
+    for tname in ("traffic_r03_lowmem.json", "traffic_r02_lowmem.json"):   # PMC passes of this same command (tools/gpu_lowmem_run.sh)
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tfile) and S["B"] == 16:
+            traffic, tsrc = json.load(open(tfile))["hbm_bytes_per_launch"], "profiles/" + tname
+            break
     return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": tsrc,
             "algorithmic_flop_per_unit": flop_unit, "kernel": "lgu::lowmem_coop_kernel (csrc/lowmem_coop.hip)",
@@ -699,7 +701,7 @@ def load_traffic(kname, cache, tiled):
     separate runs, gfx950 x2 fetch correction; tools/gpu_full_run.sh): counters cannot be collected from inside the timed
     process.  Newest round first; only a file measured in the same cache mode and layout on the same kernel is used."""
     lay = "tiled" if tiled else "rowmajor"
-    for tname in ("traffic_r02_%s_%s.json" % (cache, lay),):
+    for tname in ("traffic_r03_%s_%s.json" % (cache, lay), "traffic_r02_%s_%s.json" % (cache, lay)):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             t = json.load(open(tfile))

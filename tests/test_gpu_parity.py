@@ -1974,3 +1974,101 @@ def test_lowmem_pyramid_offset_rows_per_edge(lgu, oracle):
         lgu.ops.lowmem_pyramid_forward_mixed(f1.float(), [f.float() for f in f2s], coords, [o0, o1, None, None], 3, off_row=rows)
     with pytest.raises(RuntimeError):   # one sample per pixel
         lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords.repeat(1, 2, 1, 1, 1).contiguous(), [o0, o1, None, None], 3, off_row=rows)
+
+
+# ---- guard bands: no entry point writes outside the tensors it was given ------------------------------------------------
+# An out-of-range device write that lands inside the caching allocator's pool raises nothing and corrupts a neighbour.
+# Here every written tensor (outputs AND the in/out offsets) is a view into the middle of a larger buffer filled with a
+# sentinel; after the call the bands in front of and behind it must still hold the sentinel bit for bit.  Shapes include
+# the radii whose tap count is below the write-out's item width (9 / 25 taps: round 3 shipped, for an hour, a write-out
+# that wrote 32 tap rows whatever the radius), ragged sizes and several samples per pixel.
+_SENT = 1234.5
+
+
+def _banded(shape, dtype=None, guard=4096):
+    dtype = dtype or torch.float32
+    n = int(np.prod(shape))
+    big = torch.full((n + 2 * guard,), _SENT, dtype=dtype, device="cuda")
+    return big, big[guard:guard + n].view(shape), guard
+
+
+def _bands_intact(big, guard):
+    return bool((big[:guard] == _SENT).all()) and bool((big[-guard:] == _SENT).all())
+
+
+@pytest.mark.parametrize("half", [True, False])
+@pytest.mark.parametrize("cfg", [(2, 1, 12, 16, 64, 1, 2), (3, 1, 10, 13, 128, 2, 3), (2, 1, 24, 32, 128, 3, 4), (1, 2, 8, 16, 32, 1, 1),
+                                 (9, 1, 9, 11, 64, 3, 2)])
+def test_lowmem_entry_points_write_nothing_outside_their_tensors(lgu, cfg, half):
+    B, S, H, W, C, radius, L = cfg
+    rng = np.random.default_rng(77 + B + C + radius)
+    rd = 2 * radius + 1
+    cast = (lambda t: t.half()) if half else (lambda t: t)
+    f1 = cast(dev((rng.standard_normal((B, H, W, C)) * 0.125).astype(np.float32)))
+    f2s = [cast(dev((rng.standard_normal((B, max(H >> l, 1), max(W >> l, 1), C)) * 0.125).astype(np.float32))) for l in range(L)]
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    coords = dev((np.stack([xs, ys], -1)[None, None].repeat(B, 0).repeat(S, 1) + rng.standard_normal((B, S, H, W, 2)) * 4).astype(np.float32))
+    offs, bigs = [], []
+    for l in range(L):
+        if l < 2:
+            big, view, g = _banded((B, H, W, rd, rd, 2))
+            view.copy_(dev((4 * np.tanh(rng.standard_normal((B, H, W, rd, rd, 2)))).astype(np.float32)))
+            offs.append(view); bigs.append((big, g))
+        else:
+            offs.append(None)
+    obig, out, og = _banded((B, S, L * rd * rd, H, W))
+    bigs.append((obig, og))
+    if S == 1:
+        got = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, offs, radius, out=out)
+        assert got.data_ptr() == out.data_ptr()
+        want = lgu.ops.lowmem_pyramid_forward_mixed(f1, f2s, coords, [o.clone() if o is not None else None for o in offs], radius)
+        assert torch.equal(got, want) and not bool((got == _SENT).any())        # fully written, same as into a fresh tensor
+    else:   # several samples per pixel: the per-level operator (its output is allocated inside; the offsets are the banded tensor)
+        per_level = lgu.ops.lowMem_defSample_mixed if half else lgu.ops.lowMem_defSample
+        for l in range(L):
+            c, = per_level(f1, f2s[l], (coords / 2 ** l).contiguous(), offs[l], radius)
+            assert tuple(c.shape) == (B, S, rd, rd, H, W) and bool(torch.isfinite(c).all())
+    torch.cuda.synchronize()
+    for big, g in bigs:
+        assert _bands_intact(big, g), "a kernel wrote outside the tensor it was given"
+
+
+@pytest.mark.parametrize("tiled", [True, False])
+@pytest.mark.parametrize("probe", [True, False])
+@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 24, 40), (3, 12, 16)])
+def test_volume_path_entry_points_write_nothing_outside_their_tensors(lgu, shape, probe, tiled):
+    E, H, W = shape
+    L, R = 4, 3
+    rng = np.random.default_rng(5 + E + W)
+    vols = [dev(rng.standard_normal((E, H, W, max(H >> l, 1), max(W >> l, 1))).astype(np.float32)) for l in range(L)]
+    hw = [tuple(v.shape[3:]) for v in vols]
+    use = [lgu.ops.volume_retile(v) for v in vols] if tiled else vols
+    coords = dev(inputs.grid_coords(rng, E, H, W, 3.0))
+    bigs, offs = [], []
+    for l in range(L):
+        if l < 2:
+            big, view, g = _banded((E, H, W, 7, 7, 2))
+            view.copy_(dev((4 * np.tanh(rng.standard_normal((E, H, W, 7, 7, 2)))).astype(np.float32)))
+            offs.append(view); bigs.append((big, g))
+        else:
+            offs.append(None)
+    obig, out, og = _banded((E, L * 49, H, W))
+    bigs.append((obig, og))
+    try:
+        got = lgu.ops.defcorr_pyramid_forward(use, coords, offs, R, probe=probe, out=out, tiled=tiled, level_hw=hw if tiled else None)
+    except lgu._lib.UnsupportedShape:
+        pytest.skip("this shape / layout has no fused probe")
+    assert got.data_ptr() == out.data_ptr() and not bool((got == _SENT).any())
+    # the pyramid builder: every level it writes sits in a banded buffer of its own
+    means = dev((np.stack(np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)), -1)[None].repeat(E, 0)
+                 + rng.standard_normal((E, H, W, 2))).astype(np.float32))
+    covs = dev(rng.uniform(0.05, 5.05, (E, H, W, 2)).astype(np.float32))
+    raw = dev(rng.standard_normal((E, H, W, H, W)).astype(np.float32))
+    try:
+        levels = lgu.ops.volume_pyramid(means, covs, raw, L, 4, inplace=False, tiled=tiled)
+        assert all(bool(torch.isfinite(v).all()) for v in levels)
+    except lgu._lib.UnsupportedShape:
+        pass
+    torch.cuda.synchronize()
+    for big, g in bigs:
+        assert _bands_intact(big, g), "a kernel wrote outside the tensor it was given"

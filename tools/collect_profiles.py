@@ -2,7 +2,7 @@
 """Turns the raw rocprofv3 output of tools/gpu_full_run.sh (gpurun_out/prof_{trace,fetch,write}[_rm], prof_lm) into the
 small tracked summaries under profiles/: kernel-stats CSVs (top rows), PMC traffic JSONs (with the gfx950
 FETCH_SIZE correction) for both pyramid layouts, the low-memory kernel trace, and one combined JSON with the bench
-lines and the reference comparison.  Usage: collect_profiles.py [tag]   (default r02)"""
+lines and the reference comparison.  Usage: collect_profiles.py [tag]   (default r03)"""
 import collections
 import csv
 import glob
@@ -13,7 +13,7 @@ os.environ.setdefault("LGU_DEBUG_KNOBS", "1")   # this tool switches kernel vari
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -39,7 +39,7 @@ def layout_summary(sfx, layout):
 
     f, fd, fn = mean("prof_fetch" + sfx, "FETCH_SIZE")
     w, wd, wn = mean("prof_write" + sfx, "WRITE_SIZE")
-    cmd = "python3 bench.py --steps %d --warmup %d --no-cpu --no-extra --cache cold --layout " + layout
+    cmd = "python3 bench.py --steps %d --warmup %d --no-cpu --no-extra --no-backend --cache cold --layout " + layout
     traffic = {
         "kernel": kname,
         "pyramid_layout": layout,

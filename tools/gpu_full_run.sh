@@ -33,13 +33,13 @@ rm -rf gpurun_out/prof_trace* gpurun_out/prof_fetch* gpurun_out/prof_write* gpur
 cd /tmp
 for lay in tiled rowmajor; do
   sfx=""; [ $lay = rowmajor ] && sfx="_rm"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_trace$sfx" -- python3 "$R/bench.py" --steps 200 --warmup 20 --no-cpu --no-extra --cache cold --layout $lay > "$R/gpurun_out/prof_trace$sfx.log" 2>&1 || { echo rocprof trace $lay failed; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_fetch$sfx" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu --no-extra --cache cold --layout $lay > "$R/gpurun_out/prof_fetch$sfx.log" 2>&1 || { echo rocprof fetch $lay failed; exit 1; }
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_write$sfx" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu --no-extra --cache cold --layout $lay > "$R/gpurun_out/prof_write$sfx.log" 2>&1 || { echo rocprof write $lay failed; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_trace$sfx" -- python3 "$R/bench.py" --steps 200 --warmup 20 --no-cpu --no-extra --no-backend --cache cold --layout $lay > "$R/gpurun_out/prof_trace$sfx.log" 2>&1 || { echo rocprof trace $lay failed; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_fetch$sfx" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu --no-extra --no-backend --cache cold --layout $lay > "$R/gpurun_out/prof_fetch$sfx.log" 2>&1 || { echo rocprof fetch $lay failed; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_write$sfx" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu --no-extra --no-backend --cache cold --layout $lay > "$R/gpurun_out/prof_write$sfx.log" 2>&1 || { echo rocprof write $lay failed; exit 1; }
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_lm" -- python3 "$R/tools/prof_lowmem.py" > "$R/gpurun_out/prof_lm.log" 2>&1 || { echo rocprof lowmem failed; exit 1; }
 cd "$R"
-BENCH_ARGS="--no-extra --cache cold" bash tools/run_pmc_bench.sh > gpurun_out/pmc_cold.txt 2>&1
+BENCH_ARGS="--no-extra --no-backend --cache cold" bash tools/run_pmc_bench.sh > gpurun_out/pmc_cold.txt 2>&1
 cat gpurun_out/pmc_cold.txt
 timeout -k 10 600 python tools/compare_ref.py > gpurun_out/compare_ref.jsonl 2> gpurun_out/compare_ref.err || { tail -20 gpurun_out/compare_ref.err; exit 1; }
 cut -c1-400 gpurun_out/compare_ref.jsonl
