@@ -250,6 +250,17 @@ int lgu_volume_pyramid_det(const float* means, const float* covs, const void* de
                            int volume_half, float* const* levels, int L, int E, int H1, int W1, int H2, int W2, int radius,
                            int tiled, void* stream);
 
+/* CorrBlock.__init__'s volume, BUILT into the tiled pyramid (reference droid_slam/modules/corr.py:145-152 matmul of the
+ * two feature maps / 4 each, :64 .float(), gaussianMask_cuda.py:84-86 Gaussian re-weighting and "/ denominator + corr",
+ * corr.py:79-86 three average poolings) in ONE launch on the fp32 matrix cores: the raw all-pairs volume never reaches HBM.
+ *   fmap1, fmap2 (E, C, H, W) fp32, the reference's NCHW maps (un-scaled: the kernel applies the / 16 exactly)
+ *   means, covs (E, H, W, 2), det (E*H*W) fp32 / half (det_half) or NULL: as lgu_volume_pyramid_det
+ *   levels[l] (E, H, W, <tiled slice of (H >> l, W >> l)>) fp32, fully written incl. the slices' zero padding; L must be 4
+ * Served: H % 8 == 0, W in {16, 32, 64}, C % 16 == 0; anything else LGU_E_UNSUPPORTED (callers take the library GEMM +
+ * lgu_volume_pyramid_*).  Equal to that composition up to the GEMM's fp32 summation order. */
+int lgu_volume_build_pyramid_f32(const float* fmap1, const float* fmap2, const float* means, const float* covs, const void* det,
+                                 int det_half, float* const* levels, int L, int E, int C, int H, int W, int radius, void* stream);
+
 /* Layout conversion of `nslices` slices of H2 x W2 floats: to_tiled != 0: row-major -> tiled, else tiled -> row-major
  * (padding elements of the tiled form are written as 0).  src and dst must not overlap. */
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream);

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "liblgu_corr.so")
-SOURCES = ["capi.hip", "defcorr.hip", "defcorr_lean.hip", "defcorr_bwd.hip", "gaussmask.hip", "lowmem.hip", "lowmem_tile.hip", "lowmem_mfma.hip", "lowmem_coop.hip", "ba.hip", "ba_chol.hip", "offsets.hip", "offconv.hip"]
+SOURCES = ["capi.hip", "defcorr.hip", "defcorr_lean.hip", "defcorr_bwd.hip", "gaussmask.hip", "volbuild.hip", "lowmem.hip", "lowmem_tile.hip", "lowmem_mfma.hip", "lowmem_coop.hip", "ba.hip", "ba_chol.hip", "offsets.hip", "offconv.hip"]
 # -ffp-contract=off: keep the reference's fp32 evaluation order (no FMA contraction) so
 # results are bit-comparable with the CPU oracle; these kernels are memory-bound.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",

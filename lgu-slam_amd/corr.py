@@ -170,6 +170,8 @@ class CorrBlock:
     1x1 convolution as one library GEMM with bias and ReLU in its epilogue."""
 
     TILED_PYRAMID = True
+    FUSED_BUILD = True   # fp32 maps outside autocast: the volume is built on the matrix cores straight into the tiled pyramid
+                         # (ops.volume_build_pyramid); False = library GEMM + fused post-processing (A/B and tests)
     OUT_FORMAT = "planar"
     ENCODER = None   # a lgu_slam_amd.encoder.CorrEncoder: its first layer (1x1 convolution + ReLU) then runs INSIDE the
                      # lookup launch and __call__ returns the (1,E,128,H,W) half result of that layer; the same
@@ -183,8 +185,8 @@ class CorrBlock:
         self.ofs_residual = ofs_residual
 
         b, n, ch, h, w = fmap1.shape
-        raw = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w)  # half when the feature maps are (depth_video's)
-        volume = None                                               # raw.float() (corr.py:64), made only where needed
+        raw = None       # the all-pairs product (half when the feature maps are, depth_video's): formed only where a path needs it
+        volume = None    # raw.float() (corr.py:64), made only where needed
         feats = torch.cat((fmap1.reshape(b * n, ch, h, w), fmap2.reshape(b * n, ch, h, w)), dim=1)
         self.t = feats
         self.offset, self._zero_level = generate_offsets(ofsMap, ofs_residual, feats, num_levels)
@@ -202,6 +204,25 @@ class CorrBlock:
             # pass over the volume, level 0 in place (ops.volume_pyramid)
             mean_n, cov, det = GA.gaussian_parameters(self.t)
             tiled = bool(CorrBlock.TILED_PYRAMID) and radius == 3
+            if (tiled and CorrBlock.FUSED_BUILD and num_levels == 4 and fmap1.dtype == torch.float32 and fmap2.dtype == torch.float32
+                    and fmap1.is_cuda and not torch.is_autocast_enabled()):
+                # fp32 maps outside autocast (where the reference's matmul IS an fp32 GEMM): the product is formed on the
+                # fp32 matrix cores and goes from the accumulators into the tiled pyramid — no raw volume in HBM at all
+                # (ops.volume_build_pyramid).  Half maps / autocast keep the library GEMM, whose half rounding of the raw
+                # volume is part of what the reference computes there.
+                try:
+                    dd = det.contiguous() if det.dtype in (torch.float32, torch.float16) else det.float().contiguous()
+                    self._adopt_store(ops.volume_build_pyramid(fmap1.reshape(b * n, ch, h, w).contiguous(),
+                                                               fmap2.reshape(b * n, ch, h, w).contiguous(),
+                                                               mean_n.float().contiguous(), cov.float().contiguous(), dd,
+                                                               num_levels, GA.RADIUS))
+                    self._tiled = True
+                    raw = None
+                except _lib.UnsupportedShape:
+                    pass
+        if self._store is None and not needs_grad and hasattr(GA, "gaussian_parameters"):
+            if raw is None:
+                raw = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w)
             try:
                 # a half raw volume is converted by the builder's own load, not by a .float() pass
                 src = raw.contiguous() if raw.dtype == torch.float16 else raw.float().contiguous()
@@ -214,6 +235,8 @@ class CorrBlock:
             except _lib.UnsupportedShape:
                 self.corr_pyramid = None
         if self._store is None and self._pyr is None:
+            if raw is None:
+                raw = CorrBlock.corr(fmap1, fmap2).view(b * n, h, w, h, w)
             volume, mean_n, det = GA(self.t, raw.float())
             # pyramid over the TARGET dims: level i is (E,h,w,h/2^i,w/2^i) (reference corr.py:79-86)
             self.corr_pyramid = []

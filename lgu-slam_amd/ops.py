@@ -577,6 +577,35 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
     return levels
 
 
+def volume_build_pyramid(fmap1, fmap2, means, covs, det=None, num_levels=4, radius=4):
+    """CorrBlock.__init__'s volume built straight into the TILED pyramid (reference corr.py:145-152 matmul of the feature
+    maps / 4 each + :64 .float() + gaussianMask_cuda.py:84-86 + corr.py:79-86) in one launch on the fp32 matrix cores
+    (lgu_volume_build_pyramid_f32, csrc/volbuild.hip): the raw all-pairs volume never reaches HBM.
+    fmap1, fmap2 (E, C, H, W) fp32 contiguous (un-scaled); means, covs (E, H, W, 2); det as for volume_pyramid.
+    Returns the levels in tiled_shape form.  Raises UnsupportedShape for sizes the kernel does not serve (the caller then
+    takes matmul + volume_pyramid): H % 8, W not in {16, 32, 64}, C % 16, num_levels != 4."""
+    _check(fmap1, "fmap1", fmap2, "fmap2", means, "means", covs, "covs")
+    E, C, H, W = fmap1.shape
+    if tuple(fmap2.shape) != (E, C, H, W) or means.numel() != E * H * W * 2 or covs.numel() != E * H * W * 2:
+        raise RuntimeError("volume_build_pyramid: fmap1 / fmap2 (E,C,H,W), means / covs (E,H,W,2)")
+    if num_levels != 4:
+        raise _lib.UnsupportedShape("volume_build_pyramid: four levels")
+    levels = [torch.empty(tiled_shape(E, H, W, H >> l, W >> l), dtype=torch.float32, device=fmap1.device) for l in range(num_levels)]
+    if E == 0:
+        return levels
+    dptr, dhalf = None, 0
+    if det is not None:
+        if det.dtype not in (torch.float32, torch.float16) or not (det.is_cuda and det.is_contiguous()) or det.numel() != E * H * W:
+            raise RuntimeError("det must be a contiguous fp32 or half CUDA tensor of E*H*W elements")
+        dptr, dhalf = _ptr(det), 1 if det.dtype == torch.float16 else 0
+    lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
+    with torch.cuda.device(fmap1.device):
+        rc = _lib.load().lgu_volume_build_pyramid_f32(_ptr(fmap1), _ptr(fmap2), _ptr(means), _ptr(covs), dptr, dhalf, lp, num_levels,
+                                                      E, C, H, W, radius, _stream(fmap1))
+    _lib.check(rc, "volume_build_pyramid")
+    return levels
+
+
 def gaussian_params(mean_ofs, cov_raw, h, w, eps=1e-5):
     """Tail of GaussianMask.gaussian_parameters after the two linear heads (reference gaussianMask_cuda.py:69-83) in one
     launch: mean_ofs, cov_raw (E, h*w, 2)-shaped, both fp32 or both half.  Returns mean (E,h,w,2) fp32, cov (E,h,w,2) fp32,

@@ -2072,3 +2072,66 @@ def test_volume_path_entry_points_write_nothing_outside_their_tensors(lgu, shape
     torch.cuda.synchronize()
     for big, g in bigs:
         assert _bands_intact(big, g), "a kernel wrote outside the tensor it was given"
+
+
+@pytest.mark.parametrize("det_mode", ["none", "f32", "half"])
+@pytest.mark.parametrize("shape", [(2, 128, 16, 16), (1, 128, 24, 32), (2, 64, 48, 64), (3, 16, 8, 16), (1, 128, 48, 64)])
+def test_volume_built_on_the_matrix_cores_equals_matmul_plus_fused_builder(lgu, oracle, shape, det_mode):
+    """lgu_volume_build_pyramid_f32 (csrc/volbuild.hip): CorrBlock.__init__'s volume formed on the fp32 matrix cores and written
+    straight into the tiled 4-level pyramid == torch.matmul of the maps / 4 (reference corr.py:145-152) followed by the fused
+    post-processing (lgu_volume_pyramid_det, itself held to the oracle and the reference build), level by level INCLUDING the
+    zero padding of the tiled slices, to the GEMM's fp32 summation order (1e-5 of the level's scale); level 0 of the first
+    edge also against the C oracle's composition on the host."""
+    E, C, H, W = shape
+    rng = np.random.default_rng(900 + C + W)
+    f1 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float32))
+    f2 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float32))
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    means = dev((np.stack([xs, ys], -1)[None].repeat(E, 0) + rng.standard_normal((E, H, W, 2)) * 1.5).astype(np.float32))
+    covs = dev(rng.uniform(0.05, 5.05, (E, H, W, 2)).astype(np.float32))
+    det = None
+    if det_mode != "none":
+        det = (covs[..., 0] * covs[..., 1]).reshape(E, H * W).contiguous()
+        if det_mode == "half":
+            det = det.half()
+    got = lgu.ops.volume_build_pyramid(f1, f2, means, covs, det)
+    raw = torch.matmul((f1.reshape(E, C, H * W) / 4.0).transpose(1, 2), f2.reshape(E, C, H * W) / 4.0).view(E, H, W, H, W).contiguous()
+    want = lgu.ops.volume_pyramid(means, covs, raw.clone(), 4, 4, inplace=False, tiled=True, det=det)
+    for l in range(4):
+        assert got[l].shape == want[l].shape, l
+        scale = float(want[l].abs().max())
+        assert float((got[l] - want[l]).abs().max()) <= 1e-5 * scale, (l, float((got[l] - want[l]).abs().max()), scale)
+    if det_mode == "none":
+        lv = oracle.volume_pyramid(host(means[:1]), host(covs[:1]), host(raw[:1]), 4, 4)
+        mine0 = lgu.ops.volume_retile(got[0][:1].contiguous(), to_tiled=False, hw=(H, W))
+        assert np.abs(host(mine0) - lv[0]).max() <= 1e-5 * float(np.abs(lv[0]).max())
+
+
+def test_volume_build_refuses_what_it_does_not_serve_and_corrblock_falls_back(lgu, monkeypatch):
+    f = torch.zeros(1, 128, 12, 48, device="cuda")
+    m = torch.zeros(1, 12, 48, 2, device="cuda")
+    with pytest.raises(lgu._lib.UnsupportedShape):
+        lgu.ops.volume_build_pyramid(f, f, m, m + 1.0)        # H % 8 != 0, W = 48
+    with pytest.raises(lgu._lib.UnsupportedShape):
+        lgu.ops.volume_build_pyramid(torch.zeros(1, 12, 16, 16, device="cuda"), torch.zeros(1, 12, 16, 16, device="cuda"),
+                                     torch.zeros(1, 16, 16, 2, device="cuda"), torch.ones(1, 16, 16, 2, device="cuda"))   # C % 16
+    # CorrBlock: the matrix-core build and the library GEMM + fused post-processing give the same block (1e-5), and a shape the
+    # build does not serve takes the latter silently
+    torch.manual_seed(5)
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    for h, w, served in ((16, 32, True), (12, 16, False)):
+        GA = lgu.GaussianMask(h, w).cuda()
+        torch.nn.init.normal_(GA.meanMap.weight, 0, 0.3)
+        f1 = torch.randn(1, 2, 128, h, w, device="cuda") * 0.5
+        f2 = torch.randn(1, 2, 128, h, w, device="cuda") * 0.5
+        with torch.no_grad():
+            monkeypatch.setattr(lgu.CorrBlock, "FUSED_BUILD", True)
+            a = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+            monkeypatch.setattr(lgu.CorrBlock, "FUSED_BUILD", False)
+            b = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+        assert a._store is not None and b._store is not None and a._tiled and b._tiled
+        for l in range(4):
+            sc = float(b._store[l].abs().max())
+            d = float((a._store[l] - b._store[l]).abs().max())
+            assert d <= 1e-5 * sc and (served or d == 0.0), (h, w, l, d, sc)
