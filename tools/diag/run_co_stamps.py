@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "lgu-slam_amd", "csrc")
 EXTRA = [a for a in sys.argv[1:] if a.startswith("-D")]   # e.g. -DLGU_CO_DIAG_SAMELOAD, -DLGU_CO_DIAG_NOSCATTER (timing experiments, wrong results)
 sys.argv = [a for a in sys.argv if not a.startswith("-D")]
 subprocess.check_call(["hipcc", "-Wno-unused-value", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DLGU_MM_STAMPS", "-o", SO, os.path.join(CSRC, "lowmem_coop.hip")] + EXTRA)
+                       "-DLGU_MM_STAMPS", "-o", SO, os.path.join(CSRC, "lowmem_coop.hip"), os.path.join(CSRC, "capi.hip")] + EXTRA)
 print("build flags:", EXTRA)
 lib = ctypes.CDLL(SO)
 dev = torch.device("cuda:0")

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 SO = os.path.join(HERE, "liblgu_mmdiag.so")
 CSRC = os.path.join(ROOT, "lgu-slam_amd", "csrc")
 subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                       "-DLGU_MM_STAMPS", "-o", SO, os.path.join(CSRC, "lowmem_mfma.hip")])
+                       "-DLGU_MM_STAMPS", "-o", SO, os.path.join(CSRC, "lowmem_mfma.hip"), os.path.join(CSRC, "capi.hip")])
 lib = ctypes.CDLL(SO)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
