@@ -12,7 +12,7 @@ timeout -k 10 300 python tools/ab_lowmem_coop.py ";LGU_LOWMEM_COOP_SPLIT=0;LGU_L
 cat gpurun_out/ab_lowmem_coop.jsonl
 timeout -k 10 200 python tools/diag/run_co_stamps.py > gpurun_out/co_stamps.txt 2>&1 || { tail -5 gpurun_out/co_stamps.txt; exit 1; }
 tail -5 gpurun_out/co_stamps.txt
-{ echo "== cooperative kernel (csrc/lowmem_coop.hip), bench.py --workload lowmem =="; bash tools/run_pmc_coop.sh; echo "== one-wave-per-block kernels (csrc/lowmem_mfma.hip, LGU_LOWMEM_COOP=0) =="; LGU_LOWMEM_COOP=0 bash tools/run_pmc_coop.sh; } > gpurun_out/pmc_lowmem.txt 2>&1
+{ echo "== cooperative kernel (csrc/lowmem_coop.hip), bench.py --workload lowmem =="; bash tools/run_pmc_coop.sh; echo "== one-wave-per-block kernels (csrc/lowmem_mfma.hip, LGU_LOWMEM_COOP=0) =="; LGU_DEBUG_KNOBS=1 LGU_LOWMEM_COOP=0 bash tools/run_pmc_coop.sh; } > gpurun_out/pmc_lowmem.txt 2>&1
 cat gpurun_out/pmc_lowmem.txt
 rm -rf gpurun_out/prof_ba
 cd /tmp
