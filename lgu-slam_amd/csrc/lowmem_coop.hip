@@ -41,12 +41,10 @@ constexpr int CO_PP = 16 * CO_BOXP + 2;        // floats per patch (+2: consecut
 constexpr int CO_GUARD = 20;                   // floats in front of the patches (>= CO_BOXP + 1): see the sampling phase
 constexpr int CO_OUTP = 4 * CO_QP + 4;          // output transpose pitch
 constexpr int CO_MAXL = 4;
-// Alignment mask of the tile window's first column.  1: pairs of positions start at even columns (needed).  7 (build-time
-// A/B only): fragment loads start on 128-byte lines in the chunk-planar form — L2 read requests 4.22 -> 3.74 KB per
-// pixel-level, but the wider windows cost 2.5 % of time (112.3 against 109.6 us for config 4): not the default.
-#ifndef CO_XALIGN
-#define CO_XALIGN 1
-#endif
+// Alignment mask of the tile window's first column: pairs of positions start at even columns (needed).  (Round 2 measured
+// 7 — fragment loads starting on 128-byte lines in the chunk-planar form: L2 read requests 4.22 -> 3.74 KB per pixel-level,
+// but the wider windows cost 2.5 % of time.)
+constexpr int CO_XALIGN = 1;
 constexpr int CO_LDS_FLOATS = CO_GUARD + CO_NPX * CO_PP + CO_NPX * 4 + 2 * CO_NW + 8;
 
 struct CoParams {
@@ -131,36 +129,19 @@ __device__ unsigned long long* g_co_stamps;  // [workgroup][wave][8 per level]
   asm volatile("" : "+v"(lane));        \
   const int lx = lane & 15, lg = lane >> 4;
 
-// Compiled for 3 waves per SIMD (168 registers): at 4 (128) the look-ahead of the offsets does not fit and the kernel
-// spills; measured 141 against 107 us for BASELINE config 4.
-// Build-time A/B switches (tools/ab_lib_variants.sh), all off in the library:
-//   CO_WPS_N  waves per SIMD the kernel is compiled for (3 = 168 registers).
-//   CO_AFRESH 1 = the fmap1 fragments are loaded at the start of every level's sweep instead of once per wave life, so
-//             that they are not live across the box and sampling phases.
-//   CO_OFRESH 1 = a level's offsets and the coords are not held across its sweep but requested a second time after it.
-// AFRESH + OFRESH bring the kernel to 121 registers with no scratch, i.e. FOUR waves per SIMD (4 workgroups per CU: 151 KB
-// of LDS) — and that build runs BASELINE config 4 in 128-130 us against 111 us for the default on the same box, exactly
-// what the same source compiled for three waves per SIMD takes (129-131 us): the reloads cost 17 % and the fourth wave
-// per SIMD is worth nothing.  The kernel is not bound by occupancy.
-//   CO_TAILBREAK 1 = an odd trip count of the sweep leaves the loop before its surplus slot (which holds the last group
-//             again) instead of multiplying and storing it a second time: no change (109.9 against 109.2 us).
-//   CO_PRIO   s_setprio around the sweep (1: priority 2, 3: priority 3, 4: + priority 1 in the write-out; 2: the other phases
-//             first): 0 - 2 % on two boxes, within their noise — not adopted.
-//   CO_ABL_LOADS / _STORES / _MFMA / _SAMPLE: timing-only ablations (wrong results), profiles/r02_lowmem_coop_ablation.txt.
+// Compiled for 3 waves per SIMD (168 registers).  Build-time experiments on this kernel are made with tools/build_variant.py
+// from modified copies and recorded under profiles/ (r02_lowmem_coop_ablation.txt, r03_ab_lowmem_coop_variants.txt) — what
+// they established, in one place, so that the source carries no dead switches:
+//   * occupancy is not the bound: builds for four waves per SIMD (fragments / offsets re-requested: 121 registers; tap boxes
+//     of all levels in a prologue: 124) run no faster than three, two waves per SIMD 27 % slower;
+//   * more loads in flight make it slower (3 / 4 position fragments: + 10 / + 17 %); s_setprio around the sweep, skipping
+//     the surplus slot of odd trip counts, exec set directly around the patch stores, kernarg scalars pinned in registers,
+//     -fno-slp-vectorize / other schedulers: all within +- 2 %;
+//   * ablating fragment loads, patch stores, MFMAs and patch reads TOGETHER removes 16 % of the time;
+//   * what pays is removing a wait: a branch around a load, a loop with a load-use chain per trip.
+// CO_WPS_N: waves per SIMD the kernel is compiled for (also sizes the launcher's round rule).
 #ifndef CO_WPS_N
 #define CO_WPS_N 3
-#endif
-#ifndef CO_AFRESH
-#define CO_AFRESH 0
-#endif
-#ifndef CO_OFRESH
-#define CO_OFRESH 0
-#endif
-#ifndef CO_TAILBREAK
-#define CO_TAILBREAK 0
-#endif
-#ifndef CO_PRIO
-#define CO_PRIO 0
 #endif
 constexpr int CO_WPS = CO_WPS_N;
 template <int R, int KS>
@@ -245,9 +226,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
   // ---- once per wave life: coords of the own pixels, the first offsets, fmap1 fragments of the whole tile (requested
   // last: loads return in order, and the boxes must not wait for these 8 KB) ----
   float2 cv0[CO_QP];
-#if !CO_AFRESH
   frag a[CO_SB][KS];
-#endif
 #pragma unroll
   for (int q = 0; q < CO_QP; q++)
 #pragma unroll
@@ -273,9 +252,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       _Pragma("unroll") for (int s = 0; s < KS; s++) a[m][s] = *reinterpret_cast<const frag*>(ap + CPS * s); \
     }                                                                                       \
   }
-#if !CO_AFRESH
   CO_LOAD_A()
-#endif
 
   // (Serving the two zero-offset levels in one box / sweep / sampling pass — their 8-row patches fit one 16-row patch — was
   // built and measured: two barriers less per wave life, but 109 against 105 us; the levels stay one pass each.)
@@ -373,10 +350,6 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       if (lane == 0) { swin[wv * 2] = ulo; swin[wv * 2 + 1] = uhi; }
       CO_STAMP(1);
     }
-#if CO_AFRESH
-    frag a[CO_SB][KS];  // requested before the barrier: they travel while the other waves finish their boxes
-    CO_LOAD_A()
-#endif
     __syncthreads();
 
     // ---- phase 1: the tile window, its rows dealt to the four waves; every fragment meets all four sub-blocks ----
@@ -392,7 +365,7 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
       int TX0 = pk_lo(tlo);
       const int TY0 = pk_hi(tlo), TX1 = pk_lo(thi), TY1 = pk_hi(thi);
       if (TX1 >= TX0 && TY1 >= TY0) {
-        TX0 &= ~CO_XALIGN;  // pairs of positions start at even columns (CO_XALIGN = 1); 7: a fragment load (256 contiguous bytes per chunk in the chunk-planar form) then covers two 128-byte lines instead of three
+        TX0 &= ~CO_XALIGN;  // pairs of positions start at even columns
         // per sub-block m, this lane's pixel (m, lx): byte address in LDS of the patch entry of (row 0 of the map, column
         // 4 lg of group 0), and the row / column ranges a store must fall in
         float* sbp[CO_SB];
@@ -422,23 +395,12 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           return ((unsigned)lg * GSTR + (unsigned)x * PSTR) * (unsigned)sizeof(T);
         };
         auto load_group = [&](frag (&dstf)[KS], unsigned coff, int y) __attribute__((always_inline)) {
-#ifdef CO_ABL_LOADS   // ablation (timing only, wrong results): every fragment load reads the same aligned 1 KB
-          const unsigned off = (unsigned)(lane0 * 16) + 0u * (coff + (unsigned)y);
-#else
           const unsigned off = coff + (unsigned)y * (YSTR * (unsigned)sizeof(T));  // bytes; the row term is scalar
-#endif
 #pragma unroll
           for (int s = 0; s < KS; s++)
             dstf[s] = *reinterpret_cast<const frag*>(reinterpret_cast<const char*>(F2 + KSTR * s) + (size_t)off);
         };
         if (nit > 0) {
-#if CO_PRIO == 1 || CO_PRIO == 4
-          __builtin_amdgcn_s_setprio(2);  // A/B: waves in their sweep (loads in flight) issue first
-#elif CO_PRIO == 3
-          __builtin_amdgcn_s_setprio(3);
-#elif CO_PRIO == 2
-          __builtin_amdgcn_s_setprio(0);
-#endif
           // The loop body is branch-free around its loads (a branch around a load makes hipcc wait for nearly every
           // outstanding load at each use): the trip count is rounded up to a multiple of PF and the load cursor stops at
           // the last group, which the surplus steps load and store again.  Slot j remembers which group it holds.
@@ -469,20 +431,13 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
           for (int it = 0; it < nit; it += PF) {
 #pragma unroll
             for (int j = 0; j < PF; j++) {
-#if CO_TAILBREAK
-              if (j > 0 && it + j >= nit) break;  // odd trip count: the surplus slot holds the last group again — leave (scalar branch, no load behind it)
-#endif
               cof32x4 d[CO_SB];
 #pragma unroll
               for (int m = 0; m < CO_SB; m++) d[m] = cof32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int s = 0; s < KS; s++)
 #pragma unroll
-#ifdef CO_ABL_MFMA   // ablation (timing only): one cheap VALU op instead of the MFMA
-                for (int m = 0; m < CO_SB; m++) d[m][0] += (float)bq[j][s][0] * (float)a[m][s][0];
-#else
                 for (int m = 0; m < CO_SB; m++) d[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[j][s], a[m][s], d[m], 0, 0, 0);
-#endif
               const int y = ys[j], gq = gqs[j];
               issue(j);
               if (gq != curq) {  // wave-uniform
@@ -510,28 +465,15 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
               for (int m = 0; m < CO_SB; m++) {
                 const unsigned long long rowm = __builtin_amdgcn_ballot_w64((unsigned)(y - sylo[m]) < (unsigned)sbh[m]);
                 float* dst = sbp[m] + yg;
-#ifdef CO_ABL_STORES  // ablation (timing only): a store only where no lane passes
-                if (__builtin_amdgcn_inverse_ballot_w64(rowm & colA[m] & colB[m] & 0ull) || d[m][0] == 12345.678f) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0] + d[m][2], d[m][1] + d[m][3]);
-#else
                 if (__builtin_amdgcn_inverse_ballot_w64(rowm & colA[m])) *reinterpret_cast<float2*>(dst) = make_float2(d[m][0], d[m][1]);
                 if (__builtin_amdgcn_inverse_ballot_w64(rowm & colB[m])) *reinterpret_cast<float2*>(dst + 2) = make_float2(d[m][2], d[m][3]);
-#endif
               }
             }
           }
         }
       }
-#if CO_PRIO == 1 || CO_PRIO == 3 || CO_PRIO == 4
-      __builtin_amdgcn_s_setprio(0);
-#elif CO_PRIO == 2
-      __builtin_amdgcn_s_setprio(2);  // A/B: the box / sampling / write-out phases issue first
-#endif
       CO_STAMP(3);
     }
-#if CO_OFRESH
-    request_offsets(lvl);  // not held across the sweep: requested again, they travel during the second barrier
-    CO_LOAD_COORDS()
-#endif
     __syncthreads();
 
     // ---- phase 2: sample the patches of the wave's own pixels ----
@@ -556,18 +498,11 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
         const int h1 = by * 4 + qr0 + q, w1r = px0 + lg;
         const int pixl = msb * 16 + (qr0 + q) * 4 + lg;
         const int4 pb = *reinterpret_cast<const int4*>(pbox + pixl * 4);  // row-uniform
-#ifdef CO_ABL_SAMPLE   // ablation (timing only): no patch reads in the sampling phase
-        const bool has_patch = pb.w == 12345, fallback = false;
-#else
         const bool has_patch = pb.w != 0, fallback = pb.z < 0;
-#endif
         const bool odd = __builtin_amdgcn_ballot_w64(!has_patch) != 0;  // wave-uniform
         // patch entry of map position (0, 0): every corner of every tap lies inside the patch (phase 0)
         const int d0 = __mul24(pixl, CO_PP) - __mul24(pb.y, CO_BOXP) - (pb.x & ~1);  // 24-bit products: full rate
         const float cx = cv0[q].x * cscale, cy = cv0[q].y * cscale;
-#if CO_OFRESH
-        if (!zo && lx == CEN % 16) o0[q][CEN / 16] = make_float2(0.f, 0.f);  // the centre tap, as phase 0 left it (:80-81)
-#endif
         float q11[TI], q21[TI], q12[TI], q22[TI];  // all reads of the pass in flight before the first blend
         if (zo) {
           // one sample position per pixel: floor, fraction and the four weights once per pass (products and order are bilerp()'s)
@@ -631,9 +566,6 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
 
     // ---- write-out: corr[b][n][ix][iy][h1][w1]; the wave's own patches become its [tap][pixel] transpose tile ----
     {
-#if CO_PRIO == 4
-      __builtin_amdgcn_s_setprio(1);
-#endif
       CO_FRESH_LANE();
       float* const outt = patch + (msb * 16 + qr0 * 4) * CO_PP;  // the patches of the wave's own pixels
 #pragma unroll
@@ -675,9 +607,6 @@ __global__ __launch_bounds__(kWave* CO_NW, CO_WPS) void lowmem_coop_kernel(const
         }
       }
       CO_STAMP(5);
-#if CO_PRIO == 4
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
   }
 }

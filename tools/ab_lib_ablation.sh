@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing-only ablations of the cooperative low-memory kernel (build/ab/liblgu_<name>.so made with -DCO_ABL_*: results are
+# Timing-only ablations of the cooperative low-memory kernel (build/ab/liblgu_<name>.so made from a copy of round 2's source with
+# its -DCO_ABL_* switches — the switches were removed from the source in round 3, the record is profiles/r02_lowmem_coop_ablation.txt; results are
 # WRONG by construction, no tests are run): which part of a wave life the time of BASELINE config 4 follows.  The
 # variants are loaded through LGU_LIB_PATH; the in-tree library is never touched.
 set -o pipefail
