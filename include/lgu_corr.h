@@ -261,6 +261,18 @@ int lgu_volume_pyramid_det(const float* means, const float* covs, const void* de
 int lgu_volume_build_pyramid_f32(const float* fmap1, const float* fmap2, const float* means, const float* covs, const void* det,
                                  int det_half, float* const* levels, int L, int E, int C, int H, int W, int radius, void* stream);
 
+/* The same for HALF feature maps (the reference under autocast, factor_graph.py:90: corr.py:145-152 is then a half GEMM —
+ * exact half x half products, fp32 accumulation, one rounding of each sum to half, which this kernel applies before the
+ * .float() of corr.py:64).
+ *   feats (E, H, W, 2C) half, channel-last, the source map's C channels first then the target map's (un-scaled;
+ *   CorrBlock's `t`, corr.py:57-62)
+ *   workspace: E*H*W*2C halves of scratch, 16-byte aligned, distinct from feats (a first small launch re-orders the maps
+ *   into MFMA fragment order there; contents afterwards unspecified)
+ * Served: H % 8 == 0, W in {16, 32, 64}, C % 32 == 0.  Differs from the library half GEMM + lgu_volume_pyramid_det only where
+ * a different fp32 summation order moves a sum across a half rounding boundary (one half ulp of that raw product). */
+int lgu_volume_build_pyramid_h16(const void* feats, void* workspace, const float* means, const float* covs, const void* det,
+                                 int det_half, float* const* levels, int L, int E, int C, int H, int W, int radius, void* stream);
+
 /* Layout conversion of `nslices` slices of H2 x W2 floats: to_tiled != 0: row-major -> tiled, else tiled -> row-major
  * (padding elements of the tiled form are written as 0).  src and dst must not overlap. */
 int lgu_volume_retile_f32(const float* src, float* dst, long long nslices, int H2, int W2, int to_tiled, void* stream);

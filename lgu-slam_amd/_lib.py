@@ -30,6 +30,7 @@ SIGNATURES = {
     "lgu_volume_pyramid_h16": [_vp, _vp, _vp, ctypes.POINTER(_vp), _int, _int, _int, _int, _int, _int, _int, _int, _vp],
     "lgu_volume_pyramid_det": [_vp, _vp, _vp, _int, _vp, _int, ctypes.POINTER(_vp)] + [_int] * 8 + [_vp],
     "lgu_volume_build_pyramid_f32": [_vp] * 5 + [_int, ctypes.POINTER(_vp)] + [_int] * 6 + [_vp],
+    "lgu_volume_build_pyramid_h16": [_vp] * 5 + [_int, ctypes.POINTER(_vp)] + [_int] * 6 + [_vp],
     "lgu_gaussian_params": [_vp] * 5 + [_int] * 4 + [ctypes.c_float, _vp],
     "lgu_probe_mask_scale_f32": [_vp, _vp, _int, _int, _int, _int, _vp],
     "lgu_offset_conv_frames_h16": [_vp] * 7 + [_int] * 5 + [_vp],

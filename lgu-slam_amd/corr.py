@@ -172,6 +172,12 @@ class CorrBlock:
     TILED_PYRAMID = True
     FUSED_BUILD = True   # fp32 maps outside autocast: the volume is built on the matrix cores straight into the tiled pyramid
                          # (ops.volume_build_pyramid); False = library GEMM + fused post-processing (A/B and tests)
+    FUSED_BUILD_HALF = os.environ.get("LGU_FUSED_BUILD_HALF", "0") == "1"
+                         # half maps (autocast): the same with each product sum rounded to half in the kernel, as the
+                         # reference's half GEMM rounds it.  OPT-IN: a half GEMM fixes no summation order, so a raw product
+                         # next to a rounding boundary can land one half ulp away from this device's library GEMM (0.03 %
+                         # of the entries at 16 x 32), and the default keeps torch.matmul + the fused post-processing, which
+                         # tests hold BIT-equal to the torch composition under autocast
     OUT_FORMAT = "planar"
     ENCODER = None   # a lgu_slam_amd.encoder.CorrEncoder: its first layer (1x1 convolution + ReLU) then runs INSIDE the
                      # lookup launch and __call__ returns the (1,E,128,H,W) half result of that layer; the same
@@ -216,6 +222,17 @@ class CorrBlock:
                                                                fmap2.reshape(b * n, ch, h, w).contiguous(),
                                                                mean_n.float().contiguous(), cov.float().contiguous(), dd,
                                                                num_levels, GA.RADIUS))
+                    self._tiled = True
+                    raw = None
+                except _lib.UnsupportedShape:
+                    pass
+            elif (tiled and CorrBlock.FUSED_BUILD_HALF and num_levels == 4 and self.t.dtype == torch.float16 and self.t.is_cuda
+                    and fmap1.dtype == torch.float16 and fmap2.dtype == torch.float16):
+                # half maps: the reference's matmul is a half GEMM; the kernel rounds each product sum to half as it does
+                try:
+                    dd = det.contiguous() if det.dtype in (torch.float32, torch.float16) else det.float().contiguous()
+                    self._adopt_store(ops.volume_build_pyramid(self.t, None, mean_n.float().contiguous(), cov.float().contiguous(),
+                                                               dd, num_levels, GA.RADIUS))
                     self._tiled = True
                     raw = None
                 except _lib.UnsupportedShape:

@@ -28,16 +28,19 @@ namespace lgu {
 
 typedef float vbf32x16 __attribute__((ext_vector_type(16)));
 typedef float vbf32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct in a loop-carried array stays on the stack)
+typedef _Float16 vbh8 __attribute__((ext_vector_type(8)));
 
 constexpr int VB_M = 32;        // source pixels per workgroup
 constexpr int VB_ROWS = 8;      // target rows per strip
 constexpr int VB_THREADS = 256;
 constexpr int VB_L = 4;
-constexpr int VB_KC = 16;       // channels per chunk staged in LDS
+constexpr int VB_KC = 16;       // channels per chunk staged in LDS (fp32 maps)
+constexpr int VB_KH = 32;       // channels per register chunk (half maps): two v_mfma_f32_32x32x16_f16 per tile
 
 struct VolBuildParams {
-  const float* f1;      // (E, C, H*W) source maps
+  const float* f1;      // (E, C, H*W) source maps            (fp32 kernel)
   const float* f2;      // (E, C, H*W) target maps
+  const _Float16* th;   // both maps packed in MFMA fragment order by volume_pack_kernel (half kernel)
   const float* means;   // (E*H*W, 2)
   const float* covs;    // (E*H*W, 2)
   const void* det;      // (E*H*W) fp32 or half, or null (= cov0 * cov1)
@@ -62,7 +65,7 @@ __device__ __forceinline__ float vb_gauss_e(int x1, int y1, float mx, float my, 
   return expf(f1);
 }
 
-template <int NTW>   // 32-position tiles per wave: W = 16 * NTW
+template <int NTW, bool HALF>   // 32-position tiles per wave: W = 16 * NTW; HALF: half maps, product rounded to half
 __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBuildParams p) {
   constexpr int W = 16 * NTW, N = VB_ROWS * W, PITCH = vb_pitch(W);
   constexpr int W1 = W / 2, W2 = W / 4, W3 = W / 8;            // level widths of the strip
@@ -94,7 +97,47 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
   for (int t = 0; t < NTW; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-  {
+  if constexpr (HALF) {
+    // half maps (autocast: the reference's matmul is a half GEMM — exact half x half products, fp32 accumulation, ONE
+    // rounding of the sum to half, which the epilogue applies).  The maps arrive PACKED in MFMA fragment order
+    // (volume_pack_kernel below): [map][tile of 32 positions][k step of 16 channels][lane][8 halves], lane (h, li) holding
+    // channels 16 s + 8 h + j of position 32 tile + li — the operand of v_mfma_f32_32x32x16_f16 for that tile and step is ONE
+    // contiguous KB, 16 bytes per lane, straight into the fragment registers.  (Read channel-last, where a lane's 16 bytes
+    // sit 4 C bytes from its neighbour's, every load touched 64 lines and the texture path, at a line per clock, took as
+    // long as the whole epilogue: 0.21 of 0.42 ms at 20 edges.)  Per 32-channel chunk: 2 loads per tile, the next chunk's
+    // travelling under this chunk's MFMAs.  The maps are L2-resident (0.75 MB per edge).
+    const int S = p.C >> 4, T = HW / 32;
+    const vbh8* const fa = reinterpret_cast<const vbh8*>(p.th);
+    const size_t abase = ((size_t)(e * 2 + 0) * T + mb) * S * 64 + lane;
+    size_t bbase[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) bbase[t] = ((size_t)(e * 2 + 1) * T + s * (N / 32) + wv * NTW + t) * S * 64 + lane;
+    vbh8 a[2], b[NTW][2], na[2], nb[NTW][2];
+#define VB_FETCH_H(s0)                                                                          \
+  {                                                                                             \
+    na[0] = fa[abase + (size_t)(s0) * 64];                                                      \
+    na[1] = fa[abase + (size_t)((s0) + 1) * 64];                                                \
+    _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                           \
+      nb[t][0] = fa[bbase[t] + (size_t)(s0) * 64];                                              \
+      nb[t][1] = fa[bbase[t] + (size_t)((s0) + 1) * 64];                                        \
+    }                                                                                           \
+  }
+    VB_FETCH_H(0)
+    for (int s0 = 0; s0 < S; s0 += 2) {
+      a[0] = na[0]; a[1] = na[1];
+#pragma unroll
+      for (int t = 0; t < NTW; t++) { b[t][0] = nb[t][0]; b[t][1] = nb[t][1]; }
+      {
+        const int sn = s0 + 2 < S ? s0 + 2 : s0;                 // (after the last chunk: the same one again, unused)
+        VB_FETCH_H(sn)
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], b[t][ks], acc[t], 0, 0, 0);
+    }
+#undef VB_FETCH_H
+  } else {
     float* const Bs = reinterpret_cast<float*>(vb_smem4);       // [VB_KC][N]
     float* const As = Bs + VB_KC * N;                            // [VB_KC][VB_M]
     constexpr int BQ = VB_KC * N / 4 / VB_THREADS;               // float4s of the target chunk per thread (8 at W = 64)
@@ -159,7 +202,9 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
       for (int r8 = 0; r8 < 8; r8++) {
         const int r = half * 8 + r8;
         const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);      // 0..15 within the half
-        st0[row * PITCH + wv * (NTW * 32) + t * 32 + (lane & 31)] = acc[t][r] * 0.0625f;   // (f1/4)(f2/4): exact scaling
+        float v = acc[t][r] * 0.0625f;                           // (f1/4)(f2/4): exact scaling
+        if constexpr (HALF) v = (float)(_Float16)v;              // the half GEMM's output rounding, then corr.py:64 .float()
+        st0[row * PITCH + wv * (NTW * 32) + t * 32 + (lane & 31)] = v;
       }
     __syncthreads();
 
@@ -260,14 +305,45 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
   }
 }
 
-template <int NTW>
+// (E, H*W, 2C) half, channel-last (source channels first) -> [e][map][tile][k step][lane = 32 h + li][8]: one thread per 16 bytes
+__global__ __launch_bounds__(256) void volume_pack_kernel(const _Float16* __restrict__ feats, _Float16* __restrict__ packed,
+                                                          int C, int HW, unsigned total) {
+  const unsigned o = blockIdx.x * 256u + threadIdx.x;
+  if (o >= total) return;
+  const int S = C >> 4, T = HW / 32;
+  const unsigned lane = o & 63u;
+  unsigned q = o >> 6;
+  const unsigned st = q % (unsigned)S;  q /= (unsigned)S;
+  const unsigned tile = q % (unsigned)T;  q /= (unsigned)T;
+  const unsigned map = q & 1u, e = q >> 1;
+  const unsigned h = lane >> 5, li = lane & 31u;
+  const size_t src = ((size_t)e * HW + tile * 32u + li) * (size_t)(2 * C) + map * (unsigned)C + 16u * st + 8u * h;
+  reinterpret_cast<vbh8*>(packed)[o] = *reinterpret_cast<const vbh8*>(feats + src);
+}
+
+template <int NTW, bool HALF>
 static int launch_volume_build(const VolBuildParams& p, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)vb_lds_floats(16 * NTW);
-  if (lds > 64 * 1024) allow_max_dynamic_lds<&volume_build_kernel<NTW>>();
+  if (lds > 64 * 1024) allow_max_dynamic_lds<&volume_build_kernel<NTW, HALF>>();
   const size_t grid = (size_t)p.E * (p.H / VB_ROWS) * ((size_t)p.H * p.W / VB_M);
   if (grid >= (1ull << 31)) return LGU_E_UNSUPPORTED;
-  hipLaunchKernelGGL((volume_build_kernel<NTW>), dim3((unsigned)grid), dim3(VB_THREADS), lds, st, p);
+  hipLaunchKernelGGL((volume_build_kernel<NTW, HALF>), dim3((unsigned)grid), dim3(VB_THREADS), lds, st, p);
   return launch_status();
+}
+
+// argument checks both entries share; UNSUPPORTED: whole strips of 8 target rows, whole blocks of 32 source pixels, 2 W
+// positions per wave in 32-position MFMA tiles, whole channel chunks, 16-byte loads and stores
+static int volume_build_checks(const void* m1, const void* m2, const float* means, const float* covs, float* const* levels, int L,
+                               int E, int C, int H, int W, int radius, int kchunk) {
+  if (!m1 || !m2 || !means || !covs || !levels || E < 0 || C < 1 || H < 1 || W < 1 || radius < 0) return LGU_E_BADARG;
+  if (L != VB_L) return LGU_E_UNSUPPORTED;
+  for (int l = 0; l < L; l++)
+    if (!levels[l]) return LGU_E_BADARG;
+  if (H % VB_ROWS != 0 || (W != 16 && W != 32 && W != 64) || (H * W) % VB_M != 0 || C % kchunk != 0) return LGU_E_UNSUPPORTED;
+  if ((size_t)C * H * W >= (1u << 30)) return LGU_E_UNSUPPORTED;
+  uintptr_t al = reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2);
+  for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(levels[l]);
+  return (al & 15) ? LGU_E_UNSUPPORTED : LGU_OK;
 }
 
 }  // namespace lgu
@@ -277,28 +353,41 @@ extern "C" {
 int lgu_volume_build_pyramid_f32(const float* fmap1, const float* fmap2, const float* means, const float* covs, const void* det,
                                  int det_half, float* const* levels, int L, int E, int C, int H, int W, int radius, void* stream) {
   using namespace lgu;
-  if (!fmap1 || !fmap2 || !means || !covs || !levels || E < 0 || C < 1 || H < 1 || W < 1 || radius < 0) return LGU_E_BADARG;
-  if (L != VB_L) return LGU_E_UNSUPPORTED;
-  for (int l = 0; l < L; l++)
-    if (!levels[l]) return LGU_E_BADARG;
-  // whole strips of 8 target rows, whole blocks of 32 source pixels, 2 W positions per wave in 32-position MFMA tiles,
-  // whole chunks of VB_KC channels, 16-byte loads and stores
-  if (H % VB_ROWS != 0 || (W != 16 && W != 32 && W != 64) || (H * W) % VB_M != 0 || C % VB_KC != 0) return LGU_E_UNSUPPORTED;
-  if ((size_t)C * H * W >= (1u << 30)) return LGU_E_UNSUPPORTED;
-  uintptr_t al = 0;
-  for (int l = 0; l < L; l++) al |= reinterpret_cast<uintptr_t>(levels[l]);
-  al |= reinterpret_cast<uintptr_t>(fmap1) | reinterpret_cast<uintptr_t>(fmap2);
-  if (al & 15) return LGU_E_UNSUPPORTED;
+  const int rc = volume_build_checks(fmap1, fmap2, means, covs, levels, L, E, C, H, W, radius, VB_KC);
+  if (rc != LGU_OK) return rc;
   if (E == 0) return LGU_OK;
   VolBuildParams p;
-  p.f1 = fmap1; p.f2 = fmap2; p.means = means; p.covs = covs; p.det = det; p.det_half = det_half ? 1 : 0;
+  p.f1 = fmap1; p.f2 = fmap2; p.th = nullptr; p.means = means; p.covs = covs; p.det = det; p.det_half = det_half ? 1 : 0;
   for (int l = 0; l < VB_L; l++) p.out[l] = levels[l];
   p.E = E; p.C = C; p.H = H; p.W = W; p.r = radius;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (W) {
-    case 16: return launch_volume_build<1>(p, st);
-    case 32: return launch_volume_build<2>(p, st);
-    default: return launch_volume_build<4>(p, st);
+    case 16: return launch_volume_build<1, false>(p, st);
+    case 32: return launch_volume_build<2, false>(p, st);
+    default: return launch_volume_build<4, false>(p, st);
+  }
+}
+
+int lgu_volume_build_pyramid_h16(const void* feats, void* workspace, const float* means, const float* covs, const void* det,
+                                 int det_half, float* const* levels, int L, int E, int C, int H, int W, int radius, void* stream) {
+  using namespace lgu;
+  const int rc = volume_build_checks(feats, workspace, means, covs, levels, L, E, C, H, W, radius, VB_KH);
+  if (rc != LGU_OK) return rc;
+  if (E == 0) return LGU_OK;
+  const size_t units = (size_t)E * H * W * 2 * C / 8;             // 16-byte pieces of the maps
+  if (units >= (1ull << 32)) return LGU_E_UNSUPPORTED;
+  hipLaunchKernelGGL(volume_pack_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     static_cast<const _Float16*>(feats), static_cast<_Float16*>(workspace), C, H * W, (unsigned)units);
+  VolBuildParams p;
+  p.f1 = nullptr; p.f2 = nullptr; p.th = static_cast<const _Float16*>(workspace);
+  p.means = means; p.covs = covs; p.det = det; p.det_half = det_half ? 1 : 0;
+  for (int l = 0; l < VB_L; l++) p.out[l] = levels[l];
+  p.E = E; p.C = C; p.H = H; p.W = W; p.r = radius;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (W) {
+    case 16: return launch_volume_build<1, true>(p, st);
+    case 32: return launch_volume_build<2, true>(p, st);
+    default: return launch_volume_build<4, true>(p, st);
   }
 }
 

@@ -579,15 +579,28 @@ def volume_pyramid(means, covs, volume, num_levels, radius=4, inplace=False, til
 
 def volume_build_pyramid(fmap1, fmap2, means, covs, det=None, num_levels=4, radius=4):
     """CorrBlock.__init__'s volume built straight into the TILED pyramid (reference corr.py:145-152 matmul of the feature
-    maps / 4 each + :64 .float() + gaussianMask_cuda.py:84-86 + corr.py:79-86) in one launch on the fp32 matrix cores
-    (lgu_volume_build_pyramid_f32, csrc/volbuild.hip): the raw all-pairs volume never reaches HBM.
-    fmap1, fmap2 (E, C, H, W) fp32 contiguous (un-scaled); means, covs (E, H, W, 2); det as for volume_pyramid.
-    Returns the levels in tiled_shape form.  Raises UnsupportedShape for sizes the kernel does not serve (the caller then
-    takes matmul + volume_pyramid): H % 8, W not in {16, 32, 64}, C % 16, num_levels != 4."""
-    _check(fmap1, "fmap1", fmap2, "fmap2", means, "means", covs, "covs")
-    E, C, H, W = fmap1.shape
-    if tuple(fmap2.shape) != (E, C, H, W) or means.numel() != E * H * W * 2 or covs.numel() != E * H * W * 2:
-        raise RuntimeError("volume_build_pyramid: fmap1 / fmap2 (E,C,H,W), means / covs (E,H,W,2)")
+    maps / 4 each + :64 .float() + gaussianMask_cuda.py:84-86 + corr.py:79-86) in one launch on the matrix cores
+    (csrc/volbuild.hip): the raw all-pairs volume never reaches HBM.
+      fp32:  fmap1, fmap2 (E, C, H, W) fp32 contiguous (un-scaled)                       -> lgu_volume_build_pyramid_f32
+      half:  fmap1 = the channel-last pair (E, H, W, 2C) half (CorrBlock's `t`), fmap2 None -> lgu_volume_build_pyramid_h16
+             (the product is rounded to half as the reference's half GEMM rounds it)
+    means, covs (E, H, W, 2); det as for volume_pyramid.  Returns the levels in tiled_shape form.  Raises UnsupportedShape
+    for sizes the kernels do not serve (the caller then takes matmul + volume_pyramid): H % 8, W not in {16, 32, 64},
+    C % 16 (fp32) / C % 32 (half), num_levels != 4."""
+    half = fmap2 is None
+    if half:
+        if fmap1.dtype != torch.float16 or not (fmap1.is_cuda and fmap1.is_contiguous()) or fmap1.dim() != 4 or fmap1.shape[3] % 2:
+            raise RuntimeError("volume_build_pyramid: the half form takes one contiguous (E,H,W,2C) half CUDA tensor")
+        _check(means, "means", covs, "covs")
+        E, H, W, C2 = fmap1.shape
+        C = C2 // 2
+    else:
+        _check(fmap1, "fmap1", fmap2, "fmap2", means, "means", covs, "covs")
+        E, C, H, W = fmap1.shape
+        if tuple(fmap2.shape) != (E, C, H, W):
+            raise RuntimeError("volume_build_pyramid: fmap1 / fmap2 (E,C,H,W)")
+    if means.numel() != E * H * W * 2 or covs.numel() != E * H * W * 2:
+        raise RuntimeError("volume_build_pyramid: means / covs (E,H,W,2)")
     if num_levels != 4:
         raise _lib.UnsupportedShape("volume_build_pyramid: four levels")
     levels = [torch.empty(tiled_shape(E, H, W, H >> l, W >> l), dtype=torch.float32, device=fmap1.device) for l in range(num_levels)]
@@ -600,8 +613,13 @@ def volume_build_pyramid(fmap1, fmap2, means, covs, det=None, num_levels=4, radi
         dptr, dhalf = _ptr(det), 1 if det.dtype == torch.float16 else 0
     lp = (_vp * num_levels)(*[t.data_ptr() for t in levels])
     with torch.cuda.device(fmap1.device):
-        rc = _lib.load().lgu_volume_build_pyramid_f32(_ptr(fmap1), _ptr(fmap2), _ptr(means), _ptr(covs), dptr, dhalf, lp, num_levels,
-                                                      E, C, H, W, radius, _stream(fmap1))
+        if half:
+            work = torch.empty_like(fmap1)   # the maps in MFMA fragment order (written by the entry's first launch)
+            rc = _lib.load().lgu_volume_build_pyramid_h16(_ptr(fmap1), _ptr(work), _ptr(means), _ptr(covs), dptr, dhalf, lp,
+                                                          num_levels, E, C, H, W, radius, _stream(fmap1))
+        else:
+            rc = _lib.load().lgu_volume_build_pyramid_f32(_ptr(fmap1), _ptr(fmap2), _ptr(means), _ptr(covs), dptr, dhalf, lp,
+                                                          num_levels, E, C, H, W, radius, _stream(fmap1))
     _lib.check(rc, "volume_build_pyramid")
     return levels
 

@@ -2107,6 +2107,100 @@ def test_volume_built_on_the_matrix_cores_equals_matmul_plus_fused_builder(lgu, 
         assert np.abs(host(mine0) - lv[0]).max() <= 1e-5 * float(np.abs(lv[0]).max())
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 48, 64), (3, 64, 16, 32), (2, 32, 8, 16)], ids=["48x64x128", "16x32x64", "8x16x32"])
+@pytest.mark.parametrize("det_mode", ["half", "fp32"])
+def test_half_volume_build_equals_the_half_gemm_plus_fused_builder(lgu, shape, det_mode):
+    """lgu_volume_build_pyramid_h16: half maps (the reference under autocast: corr.py:145-152 is a half GEMM), product summed in
+    fp32 on the matrix cores and rounded to half in the kernel, then the same post-processing.
+    (a) Inputs whose product sums are exactly representable (multiples of 1/64 below 8): BIT-identical to the library half
+        GEMM + lgu_volume_pyramid_det at every level, padding included — the indexing, the channel assignment of the MFMA
+        fragments and the rounding step carry no freedom there.
+    (b) Random inputs: the two fp32 summation orders can put a sum on different sides of a half rounding boundary; every
+        level-0 entry is within ONE half ulp of its raw product times the re-weighting's gain (1 + 3 / den) of the library
+        path, and fewer than 2 % of the entries differ at all."""
+    E, C, H, W = shape
+    rng = np.random.default_rng(1200 + C + W)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    means = dev((np.stack([xs, ys], -1)[None].repeat(E, 0) + rng.standard_normal((E, H, W, 2)) * 1.5).astype(np.float32))
+    covs = dev(rng.uniform(0.05, 5.05, (E, H, W, 2)).astype(np.float32))
+    det = (covs[..., 0] * covs[..., 1]).reshape(E, H * W).contiguous()
+    if det_mode == "half":
+        det = det.half()
+
+    def both(f1, f2):
+        t = torch.cat((f1, f2), 1).permute(0, 2, 3, 1).contiguous()                     # CorrBlock's `t` (corr.py:57-62)
+        got = lgu.ops.volume_build_pyramid(t, None, means, covs, det)
+        raw = torch.matmul((f1.reshape(E, C, H * W) / 4.0).transpose(1, 2), f2.reshape(E, C, H * W) / 4.0)
+        assert raw.dtype == torch.float16
+        want = lgu.ops.volume_pyramid(means, covs, raw.view(E, H, W, H, W).contiguous(), 4, 4, inplace=False, tiled=True, det=det)
+        return got, want, raw
+
+    # (a) exact sums: entries in {-1, -.5, 0, .5, 1}
+    f1 = dev((rng.integers(-2, 3, (E, C, H, W)) * 0.5).astype(np.float16))
+    f2 = dev((rng.integers(-2, 3, (E, C, H, W)) * 0.5).astype(np.float16))
+    got, want, _ = both(f1, f2)
+    for l in range(4):
+        assert got[l].shape == want[l].shape and torch.equal(got[l], want[l]), l
+    # (b) random maps
+    f1 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float16))
+    f2 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float16))
+    got, want, raw = both(f1, f2)
+    g0 = lgu.ops.volume_retile(got[0], to_tiled=False, hw=(H, W)).view(E, H * W, H * W)
+    w0 = lgu.ops.volume_retile(want[0], to_tiled=False, hw=(H, W)).view(E, H * W, H * W)
+    rawf = raw.float().abs().clamp_min(2.0 ** -14)
+    ulp = torch.exp2(torch.floor(torch.log2(rawf)) - 10.0)
+    den = 6.28 * torch.sqrt(det.float())
+    gain = (1.0 + 3.0 / den).view(E, H * W, 1)
+    d = (g0 - w0).abs()
+    assert bool((d <= ulp * gain * 1.01 + 1e-12).all()), float((d / (ulp * gain)).max())
+    frac = float((d > 0).float().mean())
+    assert frac < 0.02, frac
+    for l in range(1, 4):
+        sc = float(want[l].abs().max())
+        assert float((got[l] - want[l]).abs().max()) <= 2e-3 * sc, l
+
+
+def test_corrblock_half_build_is_opt_in_and_agrees_with_the_library_path_to_the_half_rounding(lgu, monkeypatch):
+    """CorrBlock under autocast with half maps: the default keeps the library half GEMM; FUSED_BUILD_HALF (opt-in) builds on
+    the matrix cores (no raw volume); lookups of the two blocks agree to the half rounding of the raw products."""
+    torch.manual_seed(11)
+    h, w = 16, 32
+    ofsMap = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    ofsRes = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    GA = lgu.GaussianMask(h, w).cuda()
+    f1 = (torch.randn(1, 3, 128, h, w, device="cuda") * 0.5).half()
+    f2 = (torch.randn(1, 3, 128, h, w, device="cuda") * 0.5).half()
+    ys, xs = torch.meshgrid(torch.arange(h, device="cuda").float(), torch.arange(w, device="cuda").float(), indexing="ij")
+    coords = (torch.stack([xs, ys], -1)[None, None].repeat(1, 3, 1, 1, 1) + torch.randn(1, 3, h, w, 2, device="cuda")).contiguous()
+    calls = []
+    real = lgu.ops.volume_build_pyramid
+    monkeypatch.setattr(lgu.ops, "volume_build_pyramid", lambda *a, **k: (calls.append(a[1] is None), real(*a, **k))[1])
+    assert lgu.CorrBlock.FUSED_BUILD_HALF is False or os.environ.get("LGU_FUSED_BUILD_HALF") == "1"   # opt-in
+    outs, stores, offsets = [], [], None
+    for flag in (False, True):
+        monkeypatch.setattr(lgu.CorrBlock, "FUSED_BUILD_HALF", flag)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            blk = lgu.CorrBlock(ofsMap, ofsRes, GA, f1, f2)
+            # the half convolutions of the offset heads are not run-to-run identical under autocast (the library picks its
+            # algorithm per call): both blocks sample with the first one's offsets, so only the pyramids differ
+            if offsets is None:
+                offsets = [o.clone() for o in blk.offset]
+            blk.offset = [o.clone() for o in offsets]
+            outs.append(blk(coords)[0].float())
+        stores.append([v.clone() for v in blk._store])
+        assert calls == ([True] if flag else []), (flag, calls)
+    for l in range(4):
+        sc = float(stores[0][l].abs().max())
+        assert float((stores[0][l] - stores[1][l]).abs().max()) <= 1e-3 * sc, l    # one half ulp of a raw product, re-weighted
+    # the sampler zeroes a whole tap whose window leaves the map (defCorr_sampler_kernel.cu:76-79) and the level-1 offsets pass
+    # through the probe's mask, so a last-bit change there can switch an isolated entry: all but a sliver agree to the raw
+    # products' half rounding
+    sc = float(outs[0].abs().max())
+    d = (outs[0] - outs[1]).abs()
+    frac_off = float((d > 2e-3 * sc).float().mean())
+    assert frac_off < 1e-4, (frac_off, float(d.max()), sc)
+
+
 def test_volume_build_refuses_what_it_does_not_serve_and_corrblock_falls_back(lgu, monkeypatch):
     f = torch.zeros(1, 128, 12, 48, device="cuda")
     m = torch.zeros(1, 12, 48, 2, device="cuda")

@@ -53,4 +53,17 @@ out_bytes = sum(int(np.prod(lgu.ops.tiled_shape(E, H, W, H >> l, W >> l))) for l
 res["pyramid_bytes"] = out_bytes
 res["matrix_core_build_write_GBps"] = out_bytes / (res["matrix_core_build_ms"] * 1e-3) / 1e9
 res["gemm_TFLOPs_in_build"] = 2.0 * E * (H * W) ** 2 * C / (res["matrix_core_build_ms"] * 1e-3) / 1e12
+# half maps (autocast): library half GEMM + fused post-processing against the matrix-core build with in-kernel half rounding
+h1, h2 = f1.half(), f2.half()
+th = torch.cat((h1, h2), 1).permute(0, 2, 3, 1).contiguous()
+
+
+def half_library():
+    raw = torch.matmul((h1.reshape(E, C, H * W) / 4.0).transpose(1, 2), h2.reshape(E, C, H * W) / 4.0).view(E, H, W, H, W)
+    return lgu.ops.volume_pyramid(means, covs, raw, 4, 4, inplace=True, tiled=True)
+
+
+res["half_matmul_plus_fused_postprocessing_ms"] = timed(half_library)
+res["half_matrix_core_build_ms"] = timed(lambda: lgu.ops.volume_build_pyramid(th, None, means, covs))
+res["half_matrix_core_build_write_GBps"] = out_bytes / (res["half_matrix_core_build_ms"] * 1e-3) / 1e9
 print(json.dumps(res))
