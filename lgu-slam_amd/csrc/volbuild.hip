@@ -35,6 +35,10 @@ constexpr int VB_ROWS = 8;      // target rows per strip
 constexpr int VB_THREADS = 256;
 constexpr int VB_L = 4;
 constexpr int VB_KC = 16;       // channels per chunk staged in LDS (fp32 maps)
+constexpr int VB_EP = 16;       // source pixels per epilogue pass (8 or 16): sets the LDS footprint
+// (measured, profiles/r03_ab_volbuild_half.txt: passes of 8 pixels + a register cap for 4 or 5 workgroups per CU make both
+// kernels SLOWER — 0.50 / 0.97 ms for the half kernel against 0.38 — because under the cap the compiler gives up the operand
+// prefetch: load, wait, MFMA.  The product phase is paced by the operands' load latency, not by occupancy.)
 constexpr int VB_KH = 32;       // channels per register chunk (half maps): two v_mfma_f32_32x32x16_f16 per tile
 
 struct VolBuildParams {
@@ -50,11 +54,12 @@ struct VolBuildParams {
 };
 
 __host__ __device__ constexpr int vb_pitch(int W) { return VB_ROWS * W + 4; }
-// LDS floats: the larger of one epilogue half (16 source pixels: level 0 strip + levels 1..3 of it) and one operand chunk
-__host__ __device__ constexpr int vb_lds_floats(int W) {
-  return 16 * (vb_pitch(W) + (VB_ROWS / 2) * (W / 2) + (VB_ROWS / 4) * (W / 4) + (VB_ROWS / 8) * (W / 8)) > VB_KC * (VB_ROWS * W + VB_M)
-             ? 16 * (vb_pitch(W) + (VB_ROWS / 2) * (W / 2) + (VB_ROWS / 4) * (W / 4) + (VB_ROWS / 8) * (W / 8))
-             : VB_KC * (VB_ROWS * W + VB_M);
+// LDS floats: the larger of one epilogue pass (VB_EP source pixels: level 0 strip + levels 1..3 of it) and, for fp32 maps, one
+// operand chunk
+__host__ __device__ constexpr int vb_lds_floats(int W, bool half) {
+  const int ep = VB_EP * (vb_pitch(W) + (VB_ROWS / 2) * (W / 2) + (VB_ROWS / 4) * (W / 4) + (VB_ROWS / 8) * (W / 8));
+  const int chunk = half ? 0 : VB_KC * (VB_ROWS * W + VB_M);
+  return ep > chunk ? ep : chunk;
 }
 
 // exp(f1) of gaussianAttn.cu:59-62 (see gaussmask.hip)
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
   constexpr int W1 = W / 2, W2 = W / 4, W3 = W / 8;            // level widths of the strip
   constexpr int N1 = (VB_ROWS / 2) * W1, N2 = (VB_ROWS / 4) * W2, N3 = (VB_ROWS / 8) * W3;
   extern __shared__ float4 vb_smem4[];
-  float* const st0 = reinterpret_cast<float*>(vb_smem4);      // [16][PITCH]  level-0 strip, row-major (y, x)
-  float* const st1 = st0 + 16 * PITCH;                         // [16][N1]
-  float* const st2 = st1 + 16 * N1;                            // [16][N2]
-  float* const st3 = st2 + 16 * N2;                            // [16][N3]
+  float* const st0 = reinterpret_cast<float*>(vb_smem4);      // [VB_EP][PITCH]  level-0 strip, row-major (y, x)
+  float* const st1 = st0 + VB_EP * PITCH;                      // [VB_EP][N1]
+  float* const st2 = st1 + VB_EP * N1;                         // [VB_EP][N2]
+  float* const st3 = st2 + VB_EP * N2;                         // [VB_EP][N3]
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int HW = p.H * p.W;
@@ -108,18 +113,19 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
     // travelling under this chunk's MFMAs.  The maps are L2-resident (0.75 MB per edge).
     const int S = p.C >> 4, T = HW / 32;
     const vbh8* const fa = reinterpret_cast<const vbh8*>(p.th);
-    const size_t abase = ((size_t)(e * 2 + 0) * T + mb) * S * 64 + lane;
-    size_t bbase[NTW];
+    // (16-byte units; the host checks that the packed maps hold fewer than 2^32 of them)
+    const unsigned abase = ((unsigned)(e * 2 + 0) * T + mb) * S * 64 + lane;
+    unsigned bbase[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; t++) bbase[t] = ((size_t)(e * 2 + 1) * T + s * (N / 32) + wv * NTW + t) * S * 64 + lane;
+    for (int t = 0; t < NTW; t++) bbase[t] = ((unsigned)(e * 2 + 1) * T + s * (N / 32) + wv * NTW + t) * S * 64 + lane;
     vbh8 a[2], b[NTW][2], na[2], nb[NTW][2];
 #define VB_FETCH_H(s0)                                                                          \
   {                                                                                             \
-    na[0] = fa[abase + (size_t)(s0) * 64];                                                      \
-    na[1] = fa[abase + (size_t)((s0) + 1) * 64];                                                \
+    na[0] = fa[abase + (unsigned)(s0) * 64u];                                                   \
+    na[1] = fa[abase + (unsigned)((s0) + 1) * 64u];                                             \
     _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                           \
-      nb[t][0] = fa[bbase[t] + (size_t)(s0) * 64];                                              \
-      nb[t][1] = fa[bbase[t] + (size_t)((s0) + 1) * 64];                                        \
+      nb[t][0] = fa[bbase[t] + (unsigned)(s0) * 64u];                                           \
+      nb[t][1] = fa[bbase[t] + (unsigned)((s0) + 1) * 64u];                                     \
     }                                                                                           \
   }
     VB_FETCH_H(0)
@@ -187,29 +193,29 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
 #undef VB_FETCH
   }
 
-  // ---- epilogue, 16 source pixels at a time (accumulator registers 0..7 hold rows 0..15, 8..15 rows 16..31) ----
-  const int tp = threadIdx.x >> 4, ts = threadIdx.x & 15;       // epilogue thread: pixel of the half, 1 of 16 workers on it
-  constexpr int TPR0 = W / 8;                                    // tiles per tile row, per level
+  // ---- epilogue, VB_EP source pixels per pass (accumulator registers 4q .. 4q+3 hold rows 8q .. 8q+7) ----
+  constexpr int WK = VB_THREADS / VB_EP;                        // workers per pixel (16 or 32)
+  constexpr int RP = VB_EP / 2;                                  // accumulator registers per pass
+  const int tp = threadIdx.x / WK, ts = threadIdx.x % WK;       // epilogue thread: pixel of the pass, 1 of WK workers on it
   const int tpr[VB_L] = {p.W >> 3, ((p.W >> 1) + 7) >> 3, ((p.W >> 2) + 7) >> 3, ((p.W >> 3) + 7) >> 3};
-  (void)TPR0;
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    if (half) __syncthreads();                                   // the first half's LDS reads are done
+  for (int half = 0; half < VB_M / VB_EP; half++) {
+    if (half) __syncthreads();                                   // the previous pass's LDS reads are done
     // accumulators -> st0[row][col]:  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5),  col = lane & 31
 #pragma unroll
     for (int t = 0; t < NTW; t++)
 #pragma unroll
-      for (int r8 = 0; r8 < 8; r8++) {
-        const int r = half * 8 + r8;
-        const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);      // 0..15 within the half
+      for (int r8 = 0; r8 < RP; r8++) {
+        const int r = half * RP + r8;
+        const int row = (r8 & 3) + 8 * (r8 >> 2) + 4 * (lane >> 5);      // 0 .. VB_EP-1 within the pass
         float v = acc[t][r] * 0.0625f;                           // (f1/4)(f2/4): exact scaling
         if constexpr (HALF) v = (float)(_Float16)v;              // the half GEMM's output rounding, then corr.py:64 .float()
         st0[row * PITCH + wv * (NTW * 32) + t * 32 + (lane & 31)] = v;
       }
     __syncthreads();
 
-    // per-pixel Gaussian parameters (16 workers per pixel read the same)
-    const size_t pix = (size_t)e * HW + mb * VB_M + half * 16 + tp;
+    // per-pixel Gaussian parameters (a pixel's workers read the same)
+    const size_t pix = (size_t)e * HW + mb * VB_M + half * VB_EP + tp;
     const float mx = p.means[pix * 2 + 0], my = p.means[pix * 2 + 1];
     const float c1 = p.covs[pix * 2 + 0], c2 = p.covs[pix * 2 + 1];
     float den;
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
       const int ssz0 = ((p.H + 3) >> 2) * tpr[0] * 32;
       float4* const g0 = reinterpret_cast<float4*>(p.out[0] + pix * (size_t)ssz0 + (size_t)s * (2 * tpr[0] * 32));
 #pragma unroll
-      for (int j = 0; j < N / 64; j++) {
-        const int t4 = (ts + 16 * j) * 4;                        // tiled index of this float4 inside the strip
+      for (int j = 0; j < N / (4 * WK); j++) {
+        const int t4 = (ts + WK * j) * 4;                        // tiled index of this float4 inside the strip
         const int tile = t4 >> 5, ty = tile / (W / 8), tx = tile - ty * (W / 8);
         const int yl = ty * 4 + ((t4 & 31) >> 3), x4 = tx * 8 + (t4 & 7);
         const int row = s * VB_ROWS + yl;                        // target row in the map
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
           if (x4 + 3 >= xa && x4 + 3 <= xb) v.w = (v.w * 3.0f * vb_gauss_e(x4 + 3, row, mx, my, c1, c2)) / den + v.w;
           *reinterpret_cast<float4*>(row0 + yl * W + x4) = v;
         }
-        g0[ts + 16 * j] = v;
+        g0[ts + WK * j] = v;
       }
     }
     __syncthreads();
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
       const int ssz1 = (((p.H >> 1) + 3) >> 2) * tpr[1] * 32;
       float* const g1 = p.out[1] + pix * (size_t)ssz1 + (size_t)s * (tpr[1] * 32);
       float* const d1 = st1 + tp * N1;
-      for (int t = ts; t < tpr[1] * 32; t += 16) {              // tiled order inside the tile row (tiles may be padded in x)
+      for (int t = ts; t < tpr[1] * 32; t += WK) {              // tiled order inside the tile row (tiles may be padded in x)
         const int tile = t >> 5, y = (t & 31) >> 3, x = tile * 8 + (t & 7);
         float o = 0.0f;
         if (x < W1) {
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
       const float* const s1 = st1 + tp * N1;
       float* const d2 = st2 + tp * N2;
       const int r0 = (s & 1) * 2, nr = (s == strips - 1) ? 4 - r0 : 2;   // rows of the tile row this strip writes
-      for (int t = ts; t < nr * tpr[2] * 8; t += 16) {
+      for (int t = ts; t < nr * tpr[2] * 8; t += WK) {
         const int y = t / (tpr[2] * 8), xx = t - y * (tpr[2] * 8);          // row (relative to r0), padded column
         float o = 0.0f;
         if (y < 2 && xx < W2) {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(VB_THREADS, 2) void volume_build_kernel(const VolBu
       float* const g3 = p.out[3] + pix * (size_t)ssz3 + (size_t)(s >> 2) * (tpr[3] * 32);
       const float* const s2 = st2 + tp * N2;
       const int r0 = s & 3, nr = (s == strips - 1) ? 4 - r0 : 1;
-      for (int t = ts; t < nr * tpr[3] * 8; t += 16) {
+      for (int t = ts; t < nr * tpr[3] * 8; t += WK) {
         const int y = t / (tpr[3] * 8), xx = t - y * (tpr[3] * 8);
         float o = 0.0f;
         if (y < 1 && xx < W3) {
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256) void volume_pack_kernel(const _Float16* __rest
 
 template <int NTW, bool HALF>
 static int launch_volume_build(const VolBuildParams& p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (size_t)vb_lds_floats(16 * NTW);
+  const size_t lds = sizeof(float) * (size_t)vb_lds_floats(16 * NTW, HALF);
   if (lds > 64 * 1024) allow_max_dynamic_lds<&volume_build_kernel<NTW, HALF>>();
   const size_t grid = (size_t)p.E * (p.H / VB_ROWS) * ((size_t)p.H * p.W / VB_M);
   if (grid >= (1ull << 31)) return LGU_E_UNSUPPORTED;
