@@ -867,9 +867,13 @@ def main():
 
     # BASELINE config 5 in the same run: the multi-GPU design proper (fixed graph, chunks dealt to the ranks, all-gathers,
     # BA) — STRONG scaling; every rank takes part (collectives)
-    strong = None
+    strong, strong_error = None, None
     if not args.no_backend:
-        strong = backend_run(args, lgu_slam_amd, dev, rank, world, use_dist, args.backend_steps, 3)
+        try:
+            strong = backend_run(args, lgu_slam_amd, dev, rank, world, use_dist, args.backend_steps, 3)
+        except Exception as exc:   # the headline above is measured: a failure of this leg is reported in the line, not instead of it
+            strong_error = "%s: %s" % (type(exc).__name__, exc)
+            print("[bench] config-5 leg failed on rank %d: %s" % (rank, strong_error), file=sys.stderr)
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -934,6 +938,8 @@ def main():
                 res["strong_scaling_config5"] = keep
             else:
                 res.setdefault("extra", {})["config5_backend_n1"] = keep
+        if strong_error is not None:
+            res["strong_scaling_config5" if n_ranks > 1 else "config5_backend_error"] = {"error": strong_error}
         if not (args.no_cpu or world > 1):  # rank 0, N=1 only
             res["cpu_baseline"] = cpu_baseline(E, H1, W1, L, R)
         if exchange:
