@@ -38,7 +38,8 @@ typedef const __attribute__((address_space(1))) void oc_glb_void;
 
 // 16 bytes of zeros in device memory: what a tap outside the image loads (the select is on the ADDRESS, so the loaded
 // fragment is used as it arrives and no wait sits next to the load)
-__device__ oc_u32x4 g_oc_zero[1] = {{0u, 0u, 0u, 0u}};  // not const: keeps it in the global address space (a constant-space pointer would turn the select into flat loads)
+// (16 fragments: the small-grid kernel adds a K-step offset of up to 12 fragments to whichever pointer the select produced)
+__device__ oc_u32x4 g_oc_zero[16] = {};  // not const: keeps it in the global address space (a constant-space pointer would turn the select into flat loads)
 
 struct OffConvParams {
   const _Float16* frames;  // (NF, H, W, C) channel-last, C = 128
@@ -215,6 +216,142 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
   }
 }
 
+// ---- small grids: one or a few edges per launch (AltCorrBlock's first-edge offsets) --------------------------------
+// One edge at 60 x 80 is 75 workgroups of 64 pixels for the full-resolution head and 19 for the residual head: most CUs idle,
+// and the kernel above, one wave per SIMD, is paced per K step by (a) the latency of the weight chunk two steps ahead and (b)
+// ~150 instructions of address arithmetic in load_a (0.55 us per step measured: 40 / 55 us per launch).  This kernel is the
+// same implicit GEMM — every output element sees the same MFMA sequence, results are bit-identical — arranged for that case:
+//   * the OUTPUT CHANNELS are split over blockIdx.z, OC_NTS = 2 tiles per workgroup: 4 x the workgroups, and a step's weights
+//     are 4 KiB = one 1 KiB LDS-DMA per wave (fragment: part w >> 1, tile n0 + (w & 1));
+//   * the ring is OC_RING_S = 8 deep = the K steps of one tap (C = 128, two source frames: KS = 8), so a chunk has seven steps
+//     to arrive and one trip of the unrolled loop is one tap: the tap's pixel pointers (image bounds, zero fragment) are formed
+//     once per trip and a step's pixel load is that pointer plus a compile-time offset;
+//   * per step and wave: 1 DMA + 1 (LO: 2) pixel loads, a counted wait, one barrier, 2 LDS reads, 4 (LO: 8) MFMAs.
+constexpr int OC_NTS = 2;
+constexpr int OC_RING_S = 8;
+
+template <bool LO>
+__global__ __launch_bounds__(OC_WAVES* kWave) void offconv_small_kernel(const OffConvParams p) {
+  constexpr int RING = OC_RING_S, KS = 8, CHUNK = 2 * OC_NTS * 1024;
+  constexpr int AW = LO ? 2 : 1;                       // pixel fragments per wave and step
+  constexpr int ASLOT = OC_WAVES * AW * 1024;          // bytes of pixel fragments per ring slot
+  static_assert(CHUNK == OC_WAVES * 1024 && RING == KS, "one weight fragment per wave and step; one trip per tap");
+  extern __shared__ float4 oc_smem[];  // RING x (CHUNK + ASLOT)
+  char* const wbuf = reinterpret_cast<char*>(oc_smem);
+  char* const abuf = wbuf + RING * CHUNK;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = blockIdx.y, n0 = (int)blockIdx.z * OC_NTS;
+  const int HW = p.H * p.W;
+  const int lr = lane & 15, kg = lane >> 4;
+  const size_t fstride = (size_t)HW * p.C;
+  const size_t o1 = (size_t)p.ii[e] * fstride, o2 = (size_t)p.jj[e] * fstride;
+
+  const int pix = blockIdx.x * (OC_WAVES * 16) + w * 16 + lr;   // this lane's A-row pixel
+  const bool pv = pix < HW;
+  const int pc = pv ? pix : HW - 1;
+  const int py = pc / p.W, px = pc - py * p.W;
+
+  oc_f32x4 acc[OC_NTS];
+#pragma unroll
+  for (int n = 0; n < OC_NTS; n++) acc[n] = oc_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's weight fragment of a chunk (a tile past the last one — odd tile count — re-reads the last tile into an LDS
+  // position whose products are never stored)
+  const int wtile = n0 + (w & 1) < OC_NT ? n0 + (w & 1) : OC_NT - 1;
+  const char* const wsrc = reinterpret_cast<const char*>(p.wpack) + (size_t)((w >> 1) * OC_NT + wtile) * 1024 + lane * 16;
+  char* const wdst = wbuf + w * 1024;        // wave-uniform; the DMA adds lane * 16
+  char* const adst = abuf + w * (AW * 1024);  // this wave's private pixel fragments
+  // pixel pointers of a tap: frame ii (K steps 0..3) and frame jj (4..7); a tap outside the image points at zeros
+  struct TapPtrs { const char *q1, *q2, *l1, *l2; };
+  auto tap_ptrs = [&](int tap) {
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int yy = py + dy, xx = px + dx;
+    const bool ok = pv && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+    const size_t po = ((size_t)(ok ? yy : 0) * p.W + (ok ? xx : 0)) * p.C + kg * 8;
+    const char* const z = reinterpret_cast<const char*>(g_oc_zero);
+    TapPtrs t;
+    t.q1 = ok ? reinterpret_cast<const char*>(p.frames + o1 + po) : z;
+    t.q2 = ok ? reinterpret_cast<const char*>(p.frames + o2 + po) : z;
+    t.l1 = t.l2 = z;
+    if (LO) {
+      t.l1 = ok ? reinterpret_cast<const char*>(p.frames_lo + o1 + po) : z;
+      t.l2 = ok ? reinterpret_cast<const char*>(p.frames_lo + o2 + po) : z;
+    }
+    return t;
+  };
+  // everything a step needs arrives by LDS-DMA — the weight fragment AND the pixel fragment(s) of K step ks (compile-time
+  // after unrolling; 32 channels = 64 bytes further along the pixel's row).  No load targets a register, so the compiler's
+  // wait-count pass has nothing pending to protect and inserts no waits of its own: with register-targeted pixel loads it
+  // drained the queue (vmcnt(0)) once per tap in front of an MFMA — a full load latency with seven steps of prefetch in flight.
+#define OC_STAGE(slot, s, tp, ks)                                                                                              \
+  {                                                                                                                            \
+    __builtin_amdgcn_global_load_lds((oc_glb_void*)(wsrc + (size_t)(s) * OC_CHUNK), (oc_lds_void*)(wdst + (slot) * CHUNK), 16, 0, 0);   \
+    __builtin_amdgcn_global_load_lds((oc_glb_void*)((ks) < KS / 2 ? (tp).q1 + (ks) * 64 : (tp).q2 + ((ks) - KS / 2) * 64),      \
+                                     (oc_lds_void*)(adst + (slot) * ASLOT), 16, 0, 0);                                         \
+    if (LO)                                                                                                                    \
+      __builtin_amdgcn_global_load_lds((oc_glb_void*)((ks) < KS / 2 ? (tp).l1 + (ks) * 64 : (tp).l2 + ((ks) - KS / 2) * 64),    \
+                                       (oc_lds_void*)(adst + (slot) * ASLOT + 1024), 16, 0, 0);                                \
+  }
+
+  TapPtrs cur = tap_ptrs(0);
+#pragma unroll
+  for (int k = 0; k < RING - 1; k++) OC_STAGE(k, k, cur, k)
+  constexpr int NSTEPS = 9 * KS;
+  // fully unrolled (72 steps): at a loop header the wait-count pass loses the counts and drains the queue
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++) {
+    const TapPtrs nxt = tap_ptrs(tap < 8 ? tap + 1 : 8);   // (past the last tap: fills that nobody reads, so that every
+                                                           //  step carries the same number of operations)
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+      const int s = tap * KS + k;
+      // chunk s has landed (this wave's parts) when at most the operations of steps s + 1 .. s + RING - 2 are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * (1 + AW)) : "memory");
+      __builtin_amdgcn_s_barrier();  // ... everyone's part; ring slot (s - 1) % RING is no longer read
+      const int s2 = s + RING - 1 < NSTEPS ? s + RING - 1 : NSTEPS - 1;
+      if (k == 0) OC_STAGE(RING - 1, s2, cur, KS - 1)
+      else OC_STAGE(k - 1, s2, nxt, k - 1)
+      const char* const wb = wbuf + k * CHUNK + lane * 16;
+      const oc_half8 av = *reinterpret_cast<const oc_half8*>(adst + k * ASLOT + lane * 16);
+      oc_half8 alv;
+      if (LO) alv = *reinterpret_cast<const oc_half8*>(adst + k * ASLOT + 1024 + lane * 16);
+#pragma unroll
+      for (int n = 0; n < OC_NTS; n++) {
+        const oc_half8 bh = *reinterpret_cast<const oc_half8*>(wb + n * 1024);
+        const oc_half8 bl = *reinterpret_cast<const oc_half8*>(wb + (OC_NTS + n) * 1024);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bh, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bl, acc[n], 0, 0, 0);
+        if (LO) {
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, bh, acc[n], 0, 0, 0);
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, bl, acc[n], 0, 0, 0);
+        }
+      }
+    }
+    cur = nxt;
+  }
+#undef OC_STAGE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing fills, before the workgroup's LDS is released
+
+  // C layout: lane (kg, lr) holds pixels 4 kg .. 4 kg + 3 of the tile for channel tile*16 + lr
+  const int pix0 = blockIdx.x * (OC_WAVES * 16) + w * 16 + kg * 4;
+#pragma unroll
+  for (int n = 0; n < OC_NTS; n++) {
+    const int ch = (n0 + n) * 16 + lr;
+    if (n0 + n >= OC_NT || ch >= p.Cout || pix0 >= HW) continue;
+    const float b = p.bias ? p.bias[ch] : 0.f;
+    float* dst = p.out + ((size_t)e * p.Cout + ch) * HW + pix0;
+    const oc_f32x4 v = acc[n];
+    if (pix0 + 3 < HW && (HW & 3) == 0) {
+      *reinterpret_cast<float4*>(dst) = make_float4(v[0] + b, v[1] + b, v[2] + b, v[3] + b);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (pix0 + r < HW) dst[r] = v[r] + b;
+    }
+  }
+}
+
 // ---- per-frame partial convolutions, cached across the calls of one AltCorrBlock ----------------------------------
 // The offset heads are linear in their input cat(frame ii, frame jj): conv(cat(a, b)) = conv_A(a) + conv_B(b).  A frame is
 // the source of ~10 edges and the target of ~10 more, and one AltCorrBlock serves every chunk of an update_lowmem pass
@@ -272,8 +409,22 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
   // pixel tiles per wave: 2 (128 pixels per workgroup) unless that leaves fewer than two workgroups per CU
   const int mt = ((H * W + 127) / 128) * E >= 512 ? 2 : 1;
   const dim3 grid((H * W + 64 * mt - 1) / (64 * mt), E);
-  const size_t lds = (size_t)OC_RING * OC_CHUNK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // fewer workgroups than half the CUs (one edge per call): the small-grid kernel
+  static const bool no_small = env_int("LGU_OFFCONV_NOSMALL", 0) != 0;   // debug switch (LGU_DEBUG_KNOBS): A/B against the full form
+  if (mt == 1 && (int)(grid.x * grid.y) * 2 <= device_cu_count() && p.KS == 8 && !no_small) {
+    const dim3 g3(grid.x, grid.y, (OC_NT + OC_NTS - 1) / OC_NTS);
+    const size_t lds_s = (size_t)OC_RING_S * (2 * OC_NTS * 1024 + OC_WAVES * (frames_lo ? 2 : 1) * 1024);
+    if (frames_lo) {
+      if (lds_s > 64 * 1024) allow_max_dynamic_lds<&offconv_small_kernel<true>>();
+      hipLaunchKernelGGL(offconv_small_kernel<true>, g3, dim3(OC_WAVES * kWave), lds_s, st, p);
+    } else {
+      if (lds_s > 64 * 1024) allow_max_dynamic_lds<&offconv_small_kernel<false>>();
+      hipLaunchKernelGGL(offconv_small_kernel<false>, g3, dim3(OC_WAVES * kWave), lds_s, st, p);
+    }
+    return launch_status();
+  }
+  const size_t lds = (size_t)OC_RING * OC_CHUNK;
 #define LGU_OC(LOV, MTV) hipLaunchKernelGGL((offconv_frames_kernel<LOV, MTV>), grid, dim3(OC_WAVES * kWave), lds, st, p)
   if (frames_lo) { if (mt == 2) LGU_OC(true, 2); else LGU_OC(true, 1); }
   else { if (mt == 2) LGU_OC(false, 2); else LGU_OC(false, 1); }

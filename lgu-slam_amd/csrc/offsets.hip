@@ -57,17 +57,34 @@ template <bool HALF>
 __global__ __launch_bounds__(OF_THREADS) void offsets_stats_kernel(const OffParams p) {
   const int e = blockIdx.y, chunk = blockIdx.x;
   const int HW = p.H * p.W;
-  const size_t n = (size_t)p.C * HW;
-  const size_t per = (n + OF_CHUNKS - 1) / OF_CHUNKS;
-  const size_t lo = (size_t)chunk * per, hi = lo + per < n ? lo + per : n;
+  const unsigned n = (unsigned)p.C * (unsigned)HW;              // (host-checked: C * H * W < 2^31)
+  const unsigned per = (n + OF_CHUNKS - 1) / OF_CHUNKS;
+  const unsigned lo = (unsigned)chunk * per, hi = lo + per < n ? lo + per : n;
   const size_t b0 = (size_t)e * n, b1 = (size_t)e * p.C * p.Hl * p.Wl;
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-  for (size_t i = lo + threadIdx.x; i < hi; i += OF_THREADS) {
-    const int c = (int)(i / HW), r = (int)(i - (size_t)c * HW);
-    const int y = r / p.W, x = r - y * p.W;
-    const double a = of_load<HALF>(p.o0, b0 + i);
-    const double b = of_load<HALF>(p.o1, b1 + ((size_t)c * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
-    s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+  // eight elements per trip: their (unconditional, index-clamped) loads are issued together, then added in index order — the
+  // sums are those of a one-at-a-time loop bit for bit; that loop paid a full load latency per element (a single edge is 64
+  // workgroups for 1.9 MB)
+  constexpr int UN = 8;
+  for (unsigned i = lo + threadIdx.x; i < hi; i += OF_THREADS * UN) {
+    float a[UN], b[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+      const unsigned ij = i + (unsigned)j * OF_THREADS;
+      ok[j] = ij < hi;
+      const unsigned ic = ok[j] ? ij : hi - 1;
+      const unsigned c = ic / (unsigned)HW, r = ic - c * (unsigned)HW;
+      const int y = (int)(r / (unsigned)p.W), x = (int)(r - (unsigned)y * (unsigned)p.W);
+      a[j] = of_load<HALF>(p.o0, b0 + ic);
+      b[j] = of_load<HALF>(p.o1, b1 + ((size_t)c * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
+    }
+#pragma unroll
+    for (int j = 0; j < UN; j++)
+      if (ok[j]) {
+        const double da = a[j], db = b[j];
+        s0 += da; q0 += da * da; s1 += db; q1 += db * db;
+      }
   }
   __shared__ double red[OF_THREADS / kWave][4];
 #pragma unroll
@@ -92,30 +109,52 @@ __global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffP
   __shared__ float mask[OF_TP];      // probe form: the uncertainty mask of the tile's pixels
   const int e = blockIdx.y;
   const int HW = p.H * p.W, C = p.C;
+  // the partial sums arrive in LDS with one load per thread (read one after the other by the summing thread they cost a load
+  // latency each), then two threads add them in chunk order: deterministic, and the same order as ever
+  __shared__ double part[OF_CHUNKS * 4];
+  static_assert(OF_CHUNKS * 4 == OF_THREADS, "one partial per thread");
+  const double my_part = p.partial[(size_t)e * OF_CHUNKS * 4 + threadIdx.x];   // (in flight under the probe arithmetic below)
   const int pix0 = blockIdx.x * OF_TP;
   if (p.probe && threadIdx.x >= kWave && threadIdx.x < kWave + OF_TP) {  // the arithmetic of probe_mask_scale_kernel, on the second wave
     const int pp_ = threadIdx.x - kWave;
     float mk = 1.0f;
     if (pix0 + pp_ < HW) {
       const float* pr = p.probe + (size_t)e * p.T * HW + pix0 + pp_;
-      float mean = 0.0f;
-      for (int t = 0; t < p.T; t++) mean += pr[(size_t)t * HW];
-      mean /= (float)p.T;
-      float ss = 0.0f;
-      for (int t = 0; t < p.T; t++) {
-        const float d = pr[(size_t)t * HW] - mean;
-        ss += d * d;
+      float mean = 0.0f, ss = 0.0f;
+      if (p.T <= 9) {   // the 3 x 3 probe: the samples are fetched together (two dependent passes over memory cost 18 load latencies)
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) v[t] = pr[(size_t)(t < p.T ? t : p.T - 1) * HW];
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+          if (t < p.T) mean += v[t];
+        mean /= (float)p.T;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+          if (t < p.T) {
+            const float d = v[t] - mean;
+            ss += d * d;
+          }
+      } else {
+        for (int t = 0; t < p.T; t++) mean += pr[(size_t)t * HW];
+        mean /= (float)p.T;
+        for (int t = 0; t < p.T; t++) {
+          const float d = pr[(size_t)t * HW] - mean;
+          ss += d * d;
+        }
       }
       const float var = ss / (float)(p.T - 1);
       mk = 1.0f / (1.0f + expf(-var));
     }
     mask[pp_] = mk;
   }
-  if (threadIdx.x < 2) {  // fixed-order sum of the partials: deterministic
+  part[threadIdx.x] = my_part;
+  __syncthreads();
+  if (threadIdx.x < 2) {
     double s = 0.0, q = 0.0;
     for (int k = 0; k < OF_CHUNKS; k++) {
-      s += p.partial[((size_t)e * OF_CHUNKS + k) * 4 + threadIdx.x * 2 + 0];
-      q += p.partial[((size_t)e * OF_CHUNKS + k) * 4 + threadIdx.x * 2 + 1];
+      s += part[k * 4 + threadIdx.x * 2 + 0];
+      q += part[k * 4 + threadIdx.x * 2 + 1];
     }
     const double n = (double)C * HW;
     const double mean = s / n;
@@ -136,28 +175,46 @@ __global__ __launch_bounds__(OF_THREADS) void offsets_finalize_kernel(const OffP
   float* const t0 = of_sm;
   float* const t1 = of_sm + (size_t)C * (OF_TP + 1);
   const size_t b0 = (size_t)e * C * HW, b1 = (size_t)e * C * p.Hl * p.Wl;
-  for (int idx = threadIdx.x; idx < C * OF_TP; idx += OF_THREADS) {
-    const int c = idx / OF_TP, pp = idx - c * OF_TP;
-    const int pix = pix0 + pp;
-    if (pix >= HW) continue;
-    const int y = pix / p.W, x = pix - y * p.W;
-    const float a = of_load<HALF>(p.o0, b0 + (size_t)c * HW + pix);
-    const float b = of_load<HALF>(p.o1, b1 + ((size_t)c * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
-    float v0, v1;
-    if (HALF) {
-      v0 = of_rh(of_rh(tanhf(of_rh(of_rh(a - m0) / sd0))) * 4.0f);
-      if (p.l1_f32) {
-        v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
-      } else {
-        const float u = of_rh(of_rh(tanhf(of_rh(of_rh(b - m1) / sd1))) * 4.0f);
-        v1 = of_rh(of_rh(u + v0) / 2.0f);
-      }
-    } else {
-      v0 = tanhf((a - m0) / sd0) * 4.0f;
-      v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
+  // four elements per trip, their loads issued together (unconditional, index-clamped), as in the statistics kernel
+  constexpr int UN = 4;
+  for (int idx0 = threadIdx.x; idx0 < C * OF_TP; idx0 += OF_THREADS * UN) {
+    float av[UN], bv[UN];
+    int cc[UN], pq[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+      const int idx = idx0 + j * OF_THREADS;
+      const int ic = idx < C * OF_TP ? idx : C * OF_TP - 1;
+      cc[j] = ic / OF_TP;
+      pq[j] = ic - cc[j] * OF_TP;
+      const int pix = pix0 + pq[j];
+      ok[j] = idx < C * OF_TP && pix < HW;
+      const int pxc = pix < HW ? pix : HW - 1;
+      const int y = pxc / p.W, x = pxc - y * p.W;
+      av[j] = of_load<HALF>(p.o0, b0 + (size_t)cc[j] * HW + pxc);
+      bv[j] = of_load<HALF>(p.o1, b1 + ((size_t)cc[j] * p.Hl + of_src(y, p.sy, p.Hl)) * p.Wl + of_src(x, p.sx, p.Wl));
     }
-    t0[c * (OF_TP + 1) + pp] = v0;
-    t1[c * (OF_TP + 1) + pp] = v1;
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+      if (!ok[j]) continue;
+      const int c = cc[j], pp = pq[j];
+      const float a = av[j], b = bv[j];
+      float v0, v1;
+      if (HALF) {
+        v0 = of_rh(of_rh(tanhf(of_rh(of_rh(a - m0) / sd0))) * 4.0f);
+        if (p.l1_f32) {
+          v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
+        } else {
+          const float u = of_rh(of_rh(tanhf(of_rh(of_rh(b - m1) / sd1))) * 4.0f);
+          v1 = of_rh(of_rh(u + v0) / 2.0f);
+        }
+      } else {
+        v0 = tanhf((a - m0) / sd0) * 4.0f;
+        v1 = (tanhf((b - m1) / sd1) * 4.0f + v0) / 2.0f;
+      }
+      t0[c * (OF_TP + 1) + pp] = v0;
+      t1[c * (OF_TP + 1) + pp] = v1;
+    }
   }
   __syncthreads();
   const int npx = HW - pix0 < OF_TP ? HW - pix0 : OF_TP;
@@ -316,7 +373,7 @@ static int offsets_finalize_impl(const void* o0, const void* o1, const float* pr
   if (E < 0 || C < 1 || H < 1 || W < 1 || Hl < 1 || Wl < 1) return LGU_E_BADARG;
   if (E == 0) return LGU_OK;
   const size_t lds = sizeof(float) * 2 * (size_t)C * (OF_TP + 1);
-  if (lds > 60 * 1024 || E > 65535) return LGU_E_UNSUPPORTED;
+  if (lds > 60 * 1024 || E > 65535 || (size_t)C * H * W >= (1u << 31)) return LGU_E_UNSUPPORTED;
   OffParams p;
   p.o0 = o0; p.o1 = o1; p.out0 = out0; p.out1 = out1; p.partial = static_cast<double*>(scratch);
   p.E = E; p.C = C; p.H = H; p.W = W; p.Hl = Hl; p.Wl = Wl;
