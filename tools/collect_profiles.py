@@ -112,7 +112,8 @@ bb_split = load("bench_backend_split.json") if os.path.exists(os.path.join(G, "b
 cmp_ = [json.loads(l) for l in open(os.path.join(G, "compare_ref.jsonl"))] if os.path.exists(os.path.join(G, "compare_ref.jsonl")) else None
 import shutil
 for src, dst in (("ab_encoder.jsonl", "%s_ab_encoder_formats.jsonl"), ("e2e_calls.json", "%s_e2e_glue_calls.json"),
-                 ("prof_init.txt", "%s_corrblock_init.txt"), ("ab_final.jsonl", "%s_ab_metric_kernel_variants.jsonl"),
+                 ("prof_init.txt", "%s_corrblock_init.txt"), ("ab_volbuild.json", "%s_ab_volbuild.json"),
+                 ("prof_altcall.txt", "%s_altcorr_call.txt"), ("ab_final.jsonl", "%s_ab_metric_kernel_variants.jsonl"),
                  ("pmc_cold.txt", "%s_pmc_metric_kernel_cold.txt"), ("ab_lowmem.jsonl", "%s_ab_lowmem_levels.jsonl"),
                  ("ab_lowmem_coop.jsonl", "%s_ab_lowmem_coop.jsonl"), ("co_stamps.txt", "%s_lowmem_coop_stamps.txt"),
                  ("pmc_lowmem.txt", "%s_pmc_lowmem_kernels.txt"), ("ba_kernel_stats.csv", "%s_ba_kernel_stats.csv")):

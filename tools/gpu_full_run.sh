@@ -24,8 +24,11 @@ timeout -k 10 300 python tools/ab_cold.py 0,7,6 6 tiled,rowmajor 0,1 > gpurun_ou
 cat gpurun_out/ab_final.jsonl
 timeout -k 10 300 python tools/ab_lowmem.py 1,1:c,2:c > gpurun_out/ab_lowmem.jsonl 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python tools/e2e_calls.py > gpurun_out/e2e_calls.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-{ timeout -k 10 200 python tools/prof_init.py 20 f32 && timeout -k 10 200 python tools/prof_init.py 20 half; } 2> gpurun_out/bench.err | grep "CorrBlock.__init__" > gpurun_out/prof_init.txt || { tail -5 gpurun_out/bench.err; exit 1; }
+{ timeout -k 10 200 python tools/prof_init.py 20 f32 && timeout -k 10 200 python tools/prof_init.py 20 half && LGU_FUSED_BUILD_HALF=1 timeout -k 10 200 python tools/prof_init.py 20 half | sed 's/half=True/half=True (LGU_FUSED_BUILD_HALF=1)/'; } 2> gpurun_out/bench.err | grep "CorrBlock.__init__" > gpurun_out/prof_init.txt || { tail -5 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/prof_init.txt
+timeout -k 10 200 python tools/ab_volbuild.py 20 > gpurun_out/ab_volbuild.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 200 python tools/prof_altcall.py 2> gpurun_out/bench.err | grep "per call" > gpurun_out/prof_altcall.txt || { tail -5 gpurun_out/bench.err; exit 1; }
+cat gpurun_out/prof_altcall.txt
 python -c "import json
 for n in ('bench_lowmem','bench_backend','bench_backend_loop','bench_backend_split'):
     d=json.load(open('gpurun_out/%s.json'%n)); print(n,'value',round(d['value'],1),'ms',round(d['ms_per_step'],4), d.get('phases_ms_max_over_ranks'))"
