@@ -411,7 +411,7 @@ int lgu_offset_conv_frames_h16(const void* frames, const void* frames_lo, const 
   const dim3 grid((H * W + 64 * mt - 1) / (64 * mt), E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // fewer workgroups than half the CUs (one edge per call): the small-grid kernel
-  static const bool no_small = env_int("LGU_OFFCONV_NOSMALL", 0) != 0;   // debug switch (LGU_DEBUG_KNOBS): A/B against the full form
+  const bool no_small = env_int("LGU_OFFCONV_NOSMALL", 0) != 0;   // debug switch (honoured with LGU_DEBUG_KNOBS=1 only): the full form, for A/B runs and the identity test
   if (mt == 1 && (int)(grid.x * grid.y) * 2 <= device_cu_count() && p.KS == 8 && !no_small) {
     const dim3 g3(grid.x, grid.y, (OC_NT + OC_NTS - 1) / OC_NTS);
     const size_t lds_s = (size_t)OC_RING_S * (2 * OC_NTS * 1024 + OC_WAVES * (frames_lo ? 2 : 1) * 1024);

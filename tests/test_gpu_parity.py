@@ -1104,6 +1104,34 @@ def test_offset_head_on_the_matrix_cores_equals_the_fp32_convolution(lgu, cfg):
     assert float((got2 - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [(1, 3, 60, 80), (2, 4, 13, 21), (3, 3, 30, 40), (1, 2, 7, 9)])
+def test_small_grid_offset_convolution_is_the_full_grid_kernel_bit_for_bit(lgu, cfg, monkeypatch):
+    """One or a few edges per launch (AltCorrBlock's first-edge offsets) go to offconv_small_kernel: output channels split over
+    blockIdx.z, a ring of one tap, every operand by LDS-DMA.  Every output element sees the same MFMA sequence as in the
+    full-grid kernel (selected here with the debug switch LGU_OFFCONV_NOSMALL), so the results are EQUAL — for the plain
+    head and for the two-part input of the residual head, image borders, partial pixel tiles and the odd channel-tile count
+    (98 channels = 7 tiles in groups of 2) included."""
+    E, NF, H, W = cfg
+    torch.manual_seed(7 * E + W)
+    conv = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    frames = (torch.randn(NF, H, W, 128, device="cuda") * 0.5 / 4).half()
+    lo = (torch.randn(NF, H, W, 128, device="cuda") * 1e-4).half()
+    ii = torch.randint(0, NF, (E,), device="cuda")
+    jj = torch.randint(0, NF, (E,), device="cuda")
+    packed = lgu.ops.pack_offset_conv(conv.weight, conv.bias)
+    outs = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("LGU_OFFCONV_NOSMALL", full)
+        outs.append((_banded_call(lgu, frames, ii, jj, packed, None), _banded_call(lgu, frames, ii, jj, packed, lo)))
+    monkeypatch.delenv("LGU_OFFCONV_NOSMALL")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0.1 and not torch.equal(outs[0][0], outs[0][1])
+
+
+def _banded_call(lgu, frames, ii, jj, packed, lo):
+    return lgu.ops.offset_conv_frames(frames, ii, jj, packed, frames_lo=lo)
+
+
 def test_altcorrblock_offsets_from_frames_equal_the_general_composition(lgu, monkeypatch):
     """AltCorrBlock's inference fast path for a half pyramid (level-0 head on the matrix cores from the stored frames,
     residual head on frames pooled once per block) against the reference-shaped composition (gather, x 4, cat, float,
@@ -2031,6 +2059,64 @@ def test_lowmem_entry_points_write_nothing_outside_their_tensors(lgu, cfg, half)
     torch.cuda.synchronize()
     for big, g in bigs:
         assert _bands_intact(big, g), "a kernel wrote outside the tensor it was given"
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 32), (1, 32, 8, 16), (1, 128, 48, 64)], ids=["16x32", "8x16", "48x64"])
+def test_volume_build_entry_points_write_nothing_outside_their_tensors(lgu, shape):
+    """lgu_volume_build_pyramid_f32 / _h16 called through the C ABI with every written buffer (the four tiled levels, the
+    half form's workspace) embedded in sentinel-filled memory: results equal the operator's into fresh tensors, every level
+    is fully written (padding included) and the bands are untouched."""
+    ops, lib = lgu.ops, lgu._lib.load()
+    E, C, H, W = shape
+    rng = np.random.default_rng(31 + C + W)
+    f1 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float32))
+    f2 = dev((rng.standard_normal((E, C, H, W)) * 0.5).astype(np.float32))
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    means = dev((np.stack([xs, ys], -1)[None].repeat(E, 0) + rng.standard_normal((E, H, W, 2))).astype(np.float32))
+    covs = dev(rng.uniform(0.05, 5.05, (E, H, W, 2)).astype(np.float32))
+    th = torch.cat((f1.half(), f2.half()), 1).permute(0, 2, 3, 1).contiguous()
+    for half in (False, True):
+        want = ops.volume_build_pyramid(th, None, means, covs) if half else ops.volume_build_pyramid(f1, f2, means, covs)
+        bands = [_banded(ops.tiled_shape(E, H, W, H >> l, W >> l)) for l in range(4)]
+        lp = (ops._vp * 4)(*[b[1].data_ptr() for b in bands])
+        if half:
+            wbig, work, wg = _banded(tuple(th.shape), torch.float16)
+            rc = lib.lgu_volume_build_pyramid_h16(ops._ptr(th), ops._ptr(work), ops._ptr(means), ops._ptr(covs), None, 0, lp, 4,
+                                                  E, C, H, W, 4, ops._stream(th))
+        else:
+            rc = lib.lgu_volume_build_pyramid_f32(ops._ptr(f1), ops._ptr(f2), ops._ptr(means), ops._ptr(covs), None, 0, lp, 4,
+                                                  E, C, H, W, 4, ops._stream(f1))
+        assert rc == 0
+        torch.cuda.synchronize()
+        for l, (big, view, g) in enumerate(bands):
+            assert torch.equal(view, want[l]) and not bool((view == _SENT).any()), (half, l)
+            assert _bands_intact(big, g), (half, l)
+        if half:
+            assert _bands_intact(wbig, wg) and not bool((work == _SENT).any())
+
+
+@pytest.mark.parametrize("cfg", [(1, 2, 13, 21), (1, 2, 60, 80), (16, 8, 60, 80), (3, 3, 30, 40)])
+def test_offset_convolution_writes_nothing_outside_its_tensor(lgu, cfg):
+    """lgu_offset_conv_frames_h16 (small-grid and full-grid kernels, one- and two-part input) with the output embedded in
+    sentinel-filled memory."""
+    ops, lib = lgu.ops, lgu._lib.load()
+    E, NF, H, W = cfg
+    torch.manual_seed(3 * E + H)
+    conv = torch.nn.Conv2d(256, 98, 3, padding=1).cuda()
+    frames = (torch.randn(NF, H, W, 128, device="cuda") * 0.125).half()
+    lo = (torch.randn(NF, H, W, 128, device="cuda") * 1e-4).half()
+    ii = torch.randint(0, NF, (E,), device="cuda")
+    jj = torch.randint(0, NF, (E,), device="cuda")
+    wpack, bias, Cout, C = ops.pack_offset_conv(conv.weight, conv.bias)
+    for part in (None, lo):
+        want = ops.offset_conv_frames(frames, ii, jj, (wpack, bias, Cout, C), frames_lo=part)
+        big, out, g = _banded((E, Cout, H, W))
+        rc = lib.lgu_offset_conv_frames_h16(ops._ptr(frames), ops._ptr(part) if part is not None else None, ops._ptr(ii), ops._ptr(jj),
+                                            ops._ptr(wpack), ops._ptr(bias), ops._ptr(out), E, H, W, C, Cout, ops._stream(frames))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and not bool((out == _SENT).any())
+        assert _bands_intact(big, g), "the offset convolution wrote outside its output"
 
 
 @pytest.mark.parametrize("tiled", [True, False])
