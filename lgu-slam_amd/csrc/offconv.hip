@@ -160,6 +160,7 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
     // step s + 1 is complete when at most that many operations are outstanding (loads return in order)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + MT * (LO ? 2 : 1)) : "memory");
     __builtin_amdgcn_s_barrier();  // ... everyone's part; ring slot (s + 2) % 3 = (s - 1) % 3 is no longer read
+    asm volatile("" ::: "memory");  // (the barrier intrinsic itself does not order memory operations for the compiler)
     const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;   // past the end: refetch the last chunk (see stage)
     stage(slot == 0 ? 2 : slot - 1, s2);
     load_a(s2, an, aln);
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_small_kernel(const Of
       // chunk s has landed (this wave's parts) when at most the operations of steps s + 1 .. s + RING - 2 are outstanding
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * (1 + AW)) : "memory");
       __builtin_amdgcn_s_barrier();  // ... everyone's part; ring slot (s - 1) % RING is no longer read
+      asm volatile("" ::: "memory");  // (the barrier intrinsic itself does not order memory operations for the compiler)
       const int s2 = s + RING - 1 < NSTEPS ? s + RING - 1 : NSTEPS - 1;
       if (k == 0) OC_STAGE(RING - 1, s2, cur, KS - 1)
       else OC_STAGE(k - 1, s2, nxt, k - 1)
