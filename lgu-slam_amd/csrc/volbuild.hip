@@ -38,9 +38,10 @@ constexpr int VB_KC = 16;       // channels per chunk staged in LDS (fp32 maps)
 constexpr int VB_EP = 16;       // source pixels per epilogue pass (8 or 16): sets the LDS footprint
 // (measured, profiles/r03_ab_volbuild_half.txt: passes of 8 pixels + a register cap for 4 or 5 workgroups per CU make both
 // kernels SLOWER — 0.50 / 0.97 ms for the half kernel against 0.38 — because under the cap the compiler gives up the operand
-// prefetch: load, wait, MFMA.  Deeper chunks (4 or 8 k steps in flight) move the half kernel by -8 .. +6 % only: what the
-// product phase costs is the operands' L2 traffic — every workgroup re-reads its strip of the target map, 1.8 GB per launch
-// at 20 edges.)
+// prefetch: load, wait, MFMA.  Deeper chunks (4 or 8 k steps in flight) move the half kernel by -8 .. +6 % only.  A launch
+// takes the SUM of a product-only and an epilogue-only launch (half: 0.126 + 0.225 ms at 20 edges): the phases of the workgroups
+// sharing a CU do not overlap, and neither halving the operand traffic (two source blocks per workgroup) nor staggering the
+// workgroups' phases changes that — what is left is overlap inside a wave.)
 constexpr int VB_KH = 32;       // channels per register chunk (half maps): two v_mfma_f32_32x32x16_f16 per tile
 
 struct VolBuildParams {
