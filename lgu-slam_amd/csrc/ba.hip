@@ -52,14 +52,23 @@ __device__ __forceinline__ void rel_se3(const float* ti, const float* qi, const 
   tij[0] = tj[0] - tij[0]; tij[1] = tj[1] - tij[1]; tij[2] = tj[2] - tij[2];
 }
 
-// Sum of `v` over the workgroup's 256 threads, valid in thread 0 (and every lane of wave 0).
-__device__ __forceinline__ float block_sum(float v, float* red /* [4] */) {
-  v = wave_sum_f32(v);
+// N sums over the workgroup's 256 threads behind ONE pair of barriers: every wave reduces its N values (DPP), lane 0 parks them
+// in red[wave][i], thread i adds the four wave sums in wave order ((w0 + w1) + w2) + w3 (one sum at a time
+// behind its own pair of barriers, as the first version did, cost 180 barriers per workgroup of the build kernel; same results).  Returns, in thread
+// i < N, the sum of entry i.
+template <int N>
+__device__ __forceinline__ float block_sums(const float (&v)[N], float* red /* [4 * N] */) {
+  static_assert(N <= BA_THREADS, "one result per thread");
   const int w = threadIdx.x >> 6;
-  __syncthreads();  // `red` may still be read from the previous call
-  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();  // `red` may still be read from a previous call
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const float sw = wave_sum_f32(v[i]);
+    if ((threadIdx.x & 63) == 0) red[w * N + i] = sw;
+  }
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  const int t = threadIdx.x < N ? threadIdx.x : 0;
+  return red[t] + red[N + t] + red[2 * N + t] + red[3 * N + t];
 }
 
 // ---- projective transform, residuals, Jacobians, per-edge Hessian blocks (:176-425) ----
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
   // grid = (edges, slices): an edge's pixels are split over `slices` workgroups so that a frontend-sized graph
   // (tens of edges) still fills the 256 CUs; each writes its 90 partial sums (78 Hessian + 6 + 6 gradient entries)
   // to part[e][slice][:], ba_build_finalize_kernel adds them in slice order (deterministic) into Hs / vs.
-  __shared__ float red[4];
+  __shared__ float red[4 * 78];
   const int e = blockIdx.x;
   const int chunk = (HW + slices - 1) / slices;
   const int kbeg = blockIdx.y * chunk, kend = kbeg + chunk < HW ? kbeg + chunk : HW;
@@ -159,15 +168,13 @@ __global__ __launch_bounds__(BA_THREADS) void ba_build_kernel(
   }
   // block reductions (:369-424) into this slice's partial record: [0,78) hij, [78,84) vi, [84,90) vj
   float* const rec = part + ((size_t)e * slices + blockIdx.y) * 90;
-#pragma unroll
-  for (int l = 0; l < 78; l++) {
-    const float sum = block_sum(hij[l], red);
-    if (threadIdx.x == 0) rec[l] = sum;
-  }
-#pragma unroll
-  for (int n = 0; n < 6; n++) {
-    const float a = block_sum(vi[n], red), c = block_sum(vj[n], red);
-    if (threadIdx.x == 0) { rec[78 + n] = a; rec[84 + n] = c; }
+  {
+    const float sh = block_sums(hij, red);
+    if (threadIdx.x < 78) rec[threadIdx.x] = sh;
+    const float si = block_sums(vi, red);
+    if (threadIdx.x < 6) rec[78 + threadIdx.x] = si;
+    const float sj = block_sums(vj, red);
+    if (threadIdx.x < 6) rec[84 + threadIdx.x] = sj;
   }
 }
 
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(BA_THREADS) void ba_assemble_kernel(const float* __
 // ---- S[b] = (E[ix] * Q[kx]) E[jx]^T over the pixels (:1001-1056) ----
 __global__ __launch_bounds__(BA_THREADS) void ba_eet_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
                                                             const long long* __restrict__ idx, float* __restrict__ S, int D) {
-  __shared__ float red[4];
+  __shared__ float red[4 * 36];
   const int ix = (int)idx[blockIdx.x * 3 + 0], jx = (int)idx[blockIdx.x * 3 + 1], kx = (int)idx[blockIdx.x * 3 + 2];
   float dS[36];
 #pragma unroll
@@ -349,18 +356,15 @@ __global__ __launch_bounds__(BA_THREADS) void ba_eet_kernel(const float* __restr
 #pragma unroll
       for (int m = 0; m < 6; m++) dS[n * 6 + m] += ei[n] * ej[m];
   }
-#pragma unroll
-  for (int i = 0; i < 36; i++) {
-    const float s = block_sum(dS[i], red);
-    if (threadIdx.x == 0) S[(size_t)blockIdx.x * 36 + i] = s;
-  }
+  const float ss = block_sums(dS, red);
+  if (threadIdx.x < 36) S[(size_t)blockIdx.x * 36 + threadIdx.x] = ss;
 }
 
 // ---- v[n] = E[n] (Q[k(n)] * w[k(n)])  (:1059-1093; v is written, the caller zero-initialises nothing) ----
 __global__ __launch_bounds__(BA_THREADS) void ba_ev_kernel(const float* __restrict__ Em, const float* __restrict__ Q,
                                                            const float* __restrict__ w, const long long* __restrict__ kk,
                                                            float* __restrict__ v, int D) {
-  __shared__ float red[4];
+  __shared__ float red[4 * 6];
   const int kx = (int)kk[blockIdx.x];
   float b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = threadIdx.x; k < D; k += BA_THREADS) {
@@ -368,11 +372,8 @@ __global__ __launch_bounds__(BA_THREADS) void ba_ev_kernel(const float* __restri
 #pragma unroll
     for (int n = 0; n < 6; n++) b[n] += qw * Em[((size_t)blockIdx.x * 6 + n) * D + k];
   }
-#pragma unroll
-  for (int n = 0; n < 6; n++) {
-    const float s = block_sum(b[n], red);
-    if (threadIdx.x == 0) v[(size_t)blockIdx.x * 6 + n] = s;
-  }
+  const float sb = block_sums(b, red);
+  if (threadIdx.x < 6) v[(size_t)blockIdx.x * 6 + threadIdx.x] = sb;
 }
 
 // ---- dw[n][:] = E[n]^T x[idx[n]]; rows whose pose index is <= 0 or >= P stay zero (:1095-1115, sic) ----
