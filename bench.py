@@ -575,8 +575,8 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
         iis, jjs = ii[idx], jj[idx]
         return jjs + (iis == jjs).long()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-    phase = {"corr_block": [], "lookups": [], "exchange": [], "ba": []}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    phase = {"corr_block": [], "lookups": [], "update_standin": [], "exchange": [], "ba": []}
     # The reference builds ONE AltCorrBlock per update_lowmem call and runs `steps = 8` iterations over it
     # (factor_graph.py:256-265).  Per-call state — the feature pyramid, its chunk-planar / pooled forms and the per-frame
     # partial convolutions of the offset heads (ops.OffsetHeadCache) — is therefore rebuilt every CALL_STEPS-th iteration,
@@ -597,9 +597,11 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
         if one_launch:   # all of this rank's chunks in one lookup launch (ShardedAltCorr.lookup_all), then the update stand-in per chunk
             with torch.no_grad():
                 _, corr_all, _ = sac.lookup_all(coords1)
+            ev[5].record()   # the lookups proper end here; what follows up to ev[1] is the stand-in for the update operator
             local = sh.run_chunks(edges, ii, chunk_fn, corr_all=corr_all)
         else:
-            local = sh.run_chunks(edges, ii, chunk_fn)
+            local = sh.run_chunks(edges, ii, chunk_fn)   # (lookup and stand-in interleaved per chunk: one phase)
+            ev[5].record()
         ev[1].record()
         sh.exchange_step(edges, local, target, weight, damping)
         ev[2].record()
@@ -616,7 +618,9 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
         ev[3].record()
         if record:
             ev[3].synchronize()
-            for k, name in enumerate(("lookups", "exchange", "ba")):
+            phase["lookups"].append(ev[0].elapsed_time(ev[5]))
+            phase["update_standin"].append(ev[5].elapsed_time(ev[1]))
+            for k, name in ((1, "exchange"), (2, "ba")):
                 phase[name].append(ev[k].elapsed_time(ev[k + 1]))
             phase["corr_block"].append(ev[4].elapsed_time(ev[0]))
             step_wall.append(time.perf_counter())
@@ -642,12 +646,12 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
     gc.unfreeze()
     agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and world > 1 else True
     if use_dist:
-        t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))],
-                         device=dev, dtype=torch.float64)
+        t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba", "update_standin")] +
+                         [float(np.mean(phase["corr_block"]))], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ph = float(t[0]), [float(x) for x in t[1:]]
     else:
-        ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba")] + [float(np.mean(phase["corr_block"]))]
+        ph = [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba", "update_standin")] + [float(np.mean(phase["corr_block"]))]
     if rank == 0:
         units = E * H * W
         return {"metric": "def-corr-sample Mpix·edges/s (60×80 fmap, on-the-fly correlation, r=3, L=4; global BA step)",
@@ -663,9 +667,13 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
                                     "to its own call)" if one_launch else "one call per chunk (--chunk-loop: the reference's loop)",
                          "ba": "lgu_slam_amd.ba (experimental: parity unpinned); " + ("per-edge work on the owners, all-reduced system, replicated solve "
                                 "(--ba-split)" if args.ba_split else "replicated on every rank")},
-              "phases_ms_max_over_ranks": {"lookups": ph[0], "exchange": ph[1], "ba": ph[2],
-                                           "corr_block_per_step": ph[3]},
-              "phases_note": "lookups / exchange / ba: medians over the timed steps; corr_block_per_step: MEAN over the timed steps of "
+              "phases_ms_max_over_ranks": {"lookups": ph[0], "update_standin": ph[3], "exchange": ph[1], "ba": ph[2],
+                                           "corr_block_per_step": ph[4]},
+              "phases_note": "lookups = ShardedAltCorr.lookup_all (probe, offset heads of the calls' first edges, the lookup launch); "
+                             "update_standin = the per-chunk stand-in for the update operator (~10 small torch ops per chunk: target, weight, "
+                             "damping from the lookups; out of scope, there to feed the exchange) — with --chunk-loop the two are interleaved per "
+                             "chunk and reported together under lookups; "
+                             "lookups / update_standin / exchange / ba: medians over the timed steps; corr_block_per_step: MEAN over the timed steps of "
                              "the AltCorrBlock construction (pyramid) that every %d-th iteration starts with, as one update_lowmem "
                              "call = one block + 8 iterations in the reference; the first iteration over a new block also pays the "
                              "per-frame partial convolutions of the offset heads inside its lookups; `ms_per_step` / `value` are the wall "
