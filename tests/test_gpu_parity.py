@@ -2288,6 +2288,11 @@ def test_corrblock_half_build_is_opt_in_and_agrees_with_the_library_path_to_the_
 
 
 def test_volume_build_refuses_what_it_does_not_serve_and_corrblock_falls_back(lgu, monkeypatch):
+    # no edges: empty levels of the right shapes, nothing launched (fp32 and half forms)
+    z = torch.zeros(0, 32, 8, 16, device="cuda")
+    m0 = torch.zeros(0, 8, 16, 2, device="cuda")
+    for lv in (lgu.ops.volume_build_pyramid(z, z, m0, m0), lgu.ops.volume_build_pyramid(torch.zeros(0, 8, 16, 64, device="cuda").half(), None, m0, m0)):
+        assert [tuple(v.shape) for v in lv] == [lgu.ops.tiled_shape(0, 8, 16, 8 >> l, 16 >> l) for l in range(4)]
     f = torch.zeros(1, 128, 12, 48, device="cuda")
     m = torch.zeros(1, 12, 48, 2, device="cuda")
     with pytest.raises(lgu._lib.UnsupportedShape):
