@@ -96,7 +96,16 @@ def _zero_offsets(like, n):
     """A structurally-zero offset level (reference corr.py:132-135) for n edges without n copies of it: one zero row
     expanded over the edge dimension (stride 0).  The samplers never read or write these levels (they get NULL), and
     CorrBlock.cat / __getitem__ re-expand instead of copying; `.contiguous()` materialises the zeros if somebody asks."""
-    return torch.zeros((1,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device).expand((n,) + tuple(like.shape[1:]))
+    key = (tuple(like.shape[1:]), like.dtype, like.device)
+    row = _ZERO_ROWS.get(key)
+    if row is None:   # one zero row per shape / dtype / device for the life of the process (a fill launch per call otherwise);
+        if len(_ZERO_ROWS) >= 16:   # nothing writes through a stride-0 expansion, so sharing the row is safe
+            _ZERO_ROWS.clear()
+        row = _ZERO_ROWS[key] = torch.zeros((1,) + key[0], dtype=like.dtype, device=like.device)
+    return row.expand((n,) + key[0])
+
+
+_ZERO_ROWS = {}
 
 
 def _is_zero_expansion(t):
