@@ -644,7 +644,7 @@ def backend_run(args, lgu, dev, rank, world, use_dist, steps, warmup):
     barrier()
     wall = time.perf_counter() - t0
     gc.unfreeze()
-    agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and world > 1 else True
+    agree = sh.replicas_agree(poses, disps, target, weight, damping) if use_dist and (world > 1 or sh.REHEARSE_COLLECTIVES) else True
     if use_dist:
         t = torch.tensor([wall] + [float(np.median(phase[k])) for k in ("lookups", "exchange", "ba", "update_standin")] +
                          [float(np.mean(phase["corr_block"]))], device=dev, dtype=torch.float64)

@@ -16,6 +16,8 @@ of the single-GPU run — which keeps lowMem_defSample's `offset[b*n]` quirk (it
 chunk's FIRST edge's offsets) bit-compatible — per-edge GRU state stays on its owner
 across steps, and every source frame (its damping, its upmask) has exactly one owner.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -59,6 +61,17 @@ def _flat_all_gather(group):
     return dist.get_backend(group) == "nccl"
 
 
+# Rehearsal switch: with LGU_REHEARSE_COLLECTIVES=1 and an initialised process group, a world of ONE rank still issues every
+# collective of the sharded step (the padded all-gathers, the system all-reduces of sharded_ba_split, the replica check) instead
+# of short-cutting them — on a one-GPU box that runs the exact RCCL calls (argument shapes, dtypes, in-place forms) that N > 1 runs.
+REHEARSE_COLLECTIVES = os.environ.get("LGU_REHEARSE_COLLECTIVES", "0") == "1"
+
+
+def _single(world):
+    """True when a world of this size needs no collective (one rank and no rehearsal)."""
+    return world == 1 and not (REHEARSE_COLLECTIVES and dist.is_initialized())
+
+
 class RowExchange:
     """All-gather of row-indexed tensors with uneven row counts per rank, returned in a caller-given global order.
 
@@ -80,7 +93,7 @@ class RowExchange:
         self.counts = [int(i.numel()) for i in ids]
         self.n_global = int(n_global)
         self.cmax = max(self.counts) if self.counts else 0
-        self.flat = _flat_all_gather(group) if dist.is_initialized() and self.world > 1 else True
+        self.flat = _flat_all_gather(group) if dist.is_initialized() and not _single(self.world) else True
         dev = ids[0].device if ids else torch.device("cpu")
         self.all_ids = torch.cat(self.ids) if ids else torch.zeros(0, dtype=torch.long, device=dev)
         # position of every owned row in the padded receive buffer, in all_ids order
@@ -106,7 +119,7 @@ class RowExchange:
         if out is None and not self.complete:
             raise ValueError("rows without an owner: pass out= (they keep their previous value there)")
         tail = tuple(x.shape[1:])
-        if self.world == 1:
+        if _single(self.world):
             recv = x
         else:
             pad = x.new_empty((self.cmax,) + tail)
@@ -284,7 +297,7 @@ def sharded_update_step(edges, ii, chunk_fn, target, weight, damping, upmask=Non
 def replicas_agree(*tensors, group=None):
     """True when every rank holds bit-identical copies of the given tensors (compared through an fp64 checksum and
     the element count: one small all-reduce).  The replicated BA of a sharded step silently diverges otherwise."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _single(dist.get_world_size(group)):
         return True
     sig = torch.stack([t.detach().double().sum() + 1e-3 * t.detach().double().abs().sum() + t.numel() for t in tensors])
     lo, hi = sig.clone(), sig.clone()
@@ -341,7 +354,7 @@ def sharded_ba_split(edges, target_local, weight_local, poses, disps, intrinsics
                            "of the bundle adjustment; use sharded_ba" % edges.unprocessed.numel())
     own = edges.my_edges
     ii_o, jj_o = ii[own].contiguous(), jj[own].contiguous()
-    live = dist.is_initialized() and edges.world > 1
+    live = dist.is_initialized() and not _single(edges.world)
     group = edges.exchange.group if edges.exchange is not None else None
     on_host = live and dist.get_backend(group) != "nccl"   # gloo (tests): collectives of device tensors staged through the host
 

@@ -128,6 +128,42 @@ def test_edge_exchange_gloo_world2():
     assert all(ok for _, ok, _ in res) and res[0][2] == [4, 3]
 
 
+def _rehearsal_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import lgu_slam_amd
+    sh = lgu_slam_amd.sharded
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ii = torch.tensor([0, 0, 1, 3, 9, 9, 10, 17, 17, 18])
+        x = torch.arange(10 * 3, dtype=torch.float32).view(10, 3)
+        outs = []
+        for rehearse in (False, True):
+            sh.REHEARSE_COLLECTIVES = rehearse
+            edges = sh.ShardedEdgeSet(ii)
+            assert edges.world == 1 and sh._single(1) == (not rehearse)
+            outs.append((edges.gather(x[edges.my_edges]), edges.gather_frames(torch.arange(float(edges.my_frames.numel())), out=torch.zeros(20)),
+                         sh.replicas_agree(x)))
+        q.put(bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], x)
+                   and outs[0][2] and outs[1][2]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_can_be_rehearsed_at_world_size_one():
+    """LGU_REHEARSE_COLLECTIVES: a world of one rank with an initialised process group issues the sharded step's collectives
+    instead of short-cutting them (how the exact RCCL calls are run on a one-GPU box); results equal the short cut."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    p = ctx.Process(target=_rehearsal_worker, args=(0, 1, port, q))
+    p.start()
+    ok = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok
+
+
 def test_torch_library_registration(lgu):
     from lgu_slam_amd import torch_ops
     assert len(torch_ops.REGISTERED) == 9
