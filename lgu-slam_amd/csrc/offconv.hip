@@ -226,8 +226,9 @@ __global__ __launch_bounds__(OC_WAVES* kWave) void offconv_frames_kernel(const O
 //     are 4 KiB = one 1 KiB LDS-DMA per wave (fragment: part w >> 1, tile n0 + (w & 1));
 //   * the ring is OC_RING_S = 8 deep = the K steps of one tap (C = 128, two source frames: KS = 8), so a chunk has seven steps
 //     to arrive and one trip of the unrolled loop is one tap: the tap's pixel pointers (image bounds, zero fragment) are formed
-//     once per trip and a step's pixel load is that pointer plus a compile-time offset;
-//   * per step and wave: 1 DMA + 1 (LO: 2) pixel loads, a counted wait, one barrier, 2 LDS reads, 4 (LO: 8) MFMAs.
+//     once per trip and a step's pixel source is that pointer plus a compile-time offset;
+//   * per step and wave: 1 weight DMA + 1 (LO: 2) pixel-fragment DMAs (no load targets a register, see OC_STAGE), a counted wait,
+//     one barrier, 1 (2) + 4 LDS reads, 4 (LO: 8) MFMAs.
 constexpr int OC_NTS = 2;
 constexpr int OC_RING_S = 8;
 
